@@ -1,0 +1,102 @@
+"""ctypes binding of libglc_hip.so (include/glc.h).  There is no fallback: if the library is
+missing or a symbol cannot be bound, importing this module raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libglc_hip.so")
+
+GLC_OK, GLC_EINVAL, GLC_EHIP, GLC_ENOMEM, GLC_EFORMAT, GLC_ENODEV, GLC_EIO = 0, -1, -2, -3, -4, -5, -6
+
+
+class GlcInfo(C.Structure):
+    _fields_ = [
+        ("sample_rate", C.c_uint32),
+        ("channels", C.c_uint16),
+        ("reserved", C.c_uint16),
+        ("total_samples", C.c_uint64),
+        ("encoder_delay", C.c_uint32),
+        ("padding", C.c_uint32),
+        ("original_length", C.c_uint64),
+        ("n_frames", C.c_uint64),
+        ("n_raw_frames", C.c_uint64),
+        ("total_nnz", C.c_uint64),
+    ]
+
+
+class GlcPlan(C.Structure):
+    _fields_ = [
+        ("n_frames", C.c_uint64),
+        ("padded_len", C.c_uint64),
+        ("per_channel", C.c_uint64),
+        ("encoder_delay", C.c_uint32),
+        ("padding", C.c_uint32),
+    ]
+
+
+_vp, _u8p = C.c_void_p, C.POINTER(C.c_uint8)
+
+# name -> (restype, argtypes): every symbol include/glc.h declares
+SIGNATURES = {
+    "glc_ctx_create": (C.c_int, [C.c_int, C.c_uint32, C.POINTER(_vp)]),
+    "glc_ctx_destroy": (None, [_vp]),
+    "glc_last_error": (C.c_char_p, [_vp]),
+    "glc_ctx_stream": (_vp, [_vp]),
+    "glc_ctx_device": (C.c_int, [_vp]),
+    "glc_ctx_set_stream": (C.c_int, [_vp, _vp]),
+    "glc_ctx_synchronize": (C.c_int, [_vp]),
+    "glc_plan_encode": (C.c_int, [C.c_uint64, C.c_uint16, C.POINTER(GlcPlan)]),
+    "glc_encode": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint16, C.POINTER(_vp)]),
+    "glc_record_bytes": (C.c_uint64, [C.c_uint16]),
+    "glc_encode_range_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint16,
+                                          C.c_uint64, C.c_uint64, _vp, _vp]),
+    "glc_mdct_forward_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint16,
+                                          C.c_uint64, C.c_uint64, _vp]),
+    "glc_frames_from_records": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint16, _vp, C.c_uint64,
+                                          C.POINTER(_vp)]),
+    "glc_decoded_len": (C.c_uint64, [_vp]),
+    "glc_decode": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "glc_decode_stream_begin": (C.c_int, [_vp, _vp]),
+    "glc_decode_stream_next": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_int)]),
+    "glc_serialized_size": (C.c_uint64, [_vp]),
+    "glc_serialize": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "glc_deserialize": (C.c_int, [_vp, C.c_uint64, C.POINTER(_vp)]),
+    "glc_save": (C.c_int, [_vp, C.c_char_p]),
+    "glc_load": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    "glc_frames_free": (None, [_vp]),
+    "glc_frames_info": (C.c_int, [_vp, C.POINTER(GlcInfo)]),
+    "glc_frame_is_raw": (C.c_int, [_vp, C.c_uint64]),
+    "glc_frame_sparse": (C.c_int, [_vp, C.c_uint64, C.c_uint32, _vp, _vp, C.c_uint32,
+                                   C.POINTER(C.c_uint32)]),
+    "glc_frame_scale": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_float)]),
+    "glc_frame_raw": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "glc_ctx_tables": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp, _vp,
+                                 C.POINTER(C.c_uint32)]),
+    "glc_version": (C.c_char_p, []),
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(or `make -C gapless-lossy-codec_amd/csrc`).  There is no CPU fallback.")
+
+lib = C.CDLL(LIB_PATH)
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError if the ABI is incomplete
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class GlcError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"glc error {code}: {msg}")
+        self.code = code
+
+
+def check(rc: int, ctx=None) -> None:
+    if rc != GLC_OK:
+        msg = lib.glc_last_error(ctx) or lib.glc_last_error(None) or b""
+        raise GlcError(rc, msg.decode("utf-8", "replace"))

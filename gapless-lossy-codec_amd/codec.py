@@ -1,0 +1,278 @@
+"""Host-side mirror of the reference's codec API (src/codec.rs) over the C ABI (include/glc.h).
+
+Names, argument meaning and results follow the reference crate:
+
+    Encoder::new(sample_rate)                      src/codec.rs:406   -> Encoder(sample_rate)
+    Encoder::encode(&samples, channels)            src/codec.rs:421   -> Encoder.encode(samples, channels)
+    Decoder::new(channels, sample_rate)            src/codec.rs:581   -> Decoder(channels, sample_rate)
+    Decoder::decode(&encoded, progress)            src/codec.rs:744   -> Decoder.decode(encoded)
+    Decoder::decode_streaming(encoded, progress)   src/codec.rs:595   -> Decoder.decode_streaming(encoded)
+    save_encoded / load_encoded                    src/codec.rs:774-786
+
+The reference panics on degenerate input; here those cases raise GlcError with
+code GLC_EINVAL.  All arithmetic happens in libglc_hip.so on a gfx950 device; this module holds no
+numerics and no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from ._lib import GLC_EINVAL, GlcError, GlcInfo, GlcPlan, check, lib
+
+FRAME_SIZE = 2048        # src/codec.rs:15
+HOP_SIZE = 1024          # src/codec.rs:16
+FRAMES_PER_CHUNK = 500   # src/codec.rs:18
+
+
+@dataclass
+class AudioHeader:  # src/codec.rs:39-45
+    sample_rate: int
+    channels: int
+    total_samples: int
+
+
+@dataclass
+class GaplessInfo:  # src/codec.rs:47-53
+    encoder_delay: int
+    padding: int
+    original_length: int
+
+
+@dataclass
+class EncodedFrame:  # src/codec.rs:56-69
+    sparse_coeffs_per_channel: List[List[Tuple[int, int]]]
+    scale_factors: List[float]
+    raw_pcm: Optional[np.ndarray]
+
+
+@dataclass
+class AudioChunk:  # src/codec.rs:81-85
+    samples: np.ndarray
+    is_last: bool
+
+
+class _Frames(Sequence):
+    """Lazy `Vec<EncodedFrame>` view over a glc_frames handle."""
+
+    def __init__(self, owner: "EncodedAudio"):
+        self._o = owner
+
+    def __len__(self) -> int:
+        return self._o.info().n_frames
+
+    def __getitem__(self, f):
+        if isinstance(f, slice):
+            return [self[i] for i in range(*f.indices(len(self)))]
+        n = len(self)
+        if f < 0:
+            f += n
+        if not 0 <= f < n:
+            raise IndexError(f)
+        h = self._o._h
+        if lib.glc_frame_is_raw(h, f) == 1:
+            ln = C.c_uint64()
+            check(lib.glc_frame_raw(h, f, None, 0, C.byref(ln)))
+            raw = np.empty(ln.value, np.int16)
+            check(lib.glc_frame_raw(h, f, raw.ctypes.data_as(C.c_void_p), ln.value, C.byref(ln)))
+            return EncodedFrame([], [], raw)
+        lists, scales = [], []
+        c = 0
+        while True:
+            n_pairs = C.c_uint32()
+            if lib.glc_frame_sparse(h, f, c, None, None, 0, C.byref(n_pairs)) != 0:
+                break
+            idx = np.empty(n_pairs.value, np.uint16)
+            q = np.empty(n_pairs.value, np.int16)
+            check(lib.glc_frame_sparse(h, f, c, idx.ctypes.data_as(C.c_void_p),
+                                       q.ctypes.data_as(C.c_void_p), n_pairs.value, C.byref(n_pairs)))
+            lists.append(list(zip(idx.tolist(), q.tolist())))
+            c += 1
+        c = 0
+        while True:
+            s = C.c_float()
+            if lib.glc_frame_scale(h, f, c, C.byref(s)) != 0:
+                break
+            scales.append(s.value)
+            c += 1
+        return EncodedFrame(lists, scales, None)
+
+
+class EncodedAudio:
+    """src/codec.rs:31-37; owns a library-side glc_frames object."""
+
+    def __init__(self, handle: int):
+        self._h = C.c_void_p(handle)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.glc_frames_free(h)
+
+    def info(self) -> GlcInfo:
+        i = GlcInfo()
+        check(lib.glc_frames_info(self._h, C.byref(i)))
+        return i
+
+    @property
+    def header(self) -> AudioHeader:
+        i = self.info()
+        return AudioHeader(i.sample_rate, i.channels, i.total_samples)
+
+    @property
+    def gapless_info(self) -> GaplessInfo:
+        i = self.info()
+        return GaplessInfo(i.encoder_delay, i.padding, i.original_length)
+
+    @property
+    def frames(self) -> _Frames:
+        return _Frames(self)
+
+    def to_bytes(self) -> bytes:
+        """bincode::serialize(encoded) — the .glc byte stream (src/codec.rs:776)."""
+        n = lib.glc_serialized_size(self._h)
+        buf = (C.c_uint8 * n)()
+        w = C.c_uint64()
+        check(lib.glc_serialize(self._h, buf, n, C.byref(w)))
+        return bytes(buf)
+
+    @staticmethod
+    def from_bytes(data: bytes) -> "EncodedAudio":
+        """bincode::deserialize (src/codec.rs:784)."""
+        arr = np.frombuffer(data, np.uint8)
+        out = C.c_void_p()
+        check(lib.glc_deserialize(arr.ctypes.data_as(C.c_void_p), arr.size, C.byref(out)))
+        return EncodedAudio(out.value)
+
+    @staticmethod
+    def from_records(sample_rate: int, n_samples: int, channels: int, records: np.ndarray) -> "EncodedAudio":
+        """Assemble from the device path's fixed-size frame records (all shards, frame order)."""
+        records = np.ascontiguousarray(records, np.uint8).reshape(-1)
+        rec = lib.glc_record_bytes(channels)
+        if rec == 0 or records.size % rec:
+            raise GlcError(GLC_EINVAL, "record buffer is not a whole number of records")
+        out = C.c_void_p()
+        check(lib.glc_frames_from_records(sample_rate, n_samples, channels,
+                                          records.ctypes.data_as(C.c_void_p), records.size // rec,
+                                          C.byref(out)))
+        return EncodedAudio(out.value)
+
+
+def plan_encode(n_samples: int, channels: int) -> GlcPlan:
+    """Frame count / padding of Encoder::encode (src/codec.rs:433-455); raises where it panics."""
+    p = GlcPlan()
+    check(lib.glc_plan_encode(n_samples, channels, C.byref(p)))
+    return p
+
+
+class _Ctx:
+    def __init__(self, sample_rate: int, device: int):
+        h = C.c_void_p()
+        check(lib.glc_ctx_create(device, sample_rate, C.byref(h)))
+        self._h = h
+        self.sample_rate = sample_rate
+        self.device = device
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.glc_ctx_destroy(h)
+
+    def close(self):
+        self.__del__()
+
+    def tables(self):
+        """(cos_table[1024,2048], window[2048], norm, weights[1024], band_edges)."""
+        T = np.empty((HOP_SIZE, FRAME_SIZE), np.float32)
+        w = np.empty(FRAME_SIZE, np.float32)
+        wt = np.empty(HOP_SIZE, np.float32)
+        e = np.zeros(64, np.uint32)
+        n = C.c_float()
+        ne = C.c_uint32()
+        check(lib.glc_ctx_tables(self._h, T.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p),
+                                 C.byref(n), wt.ctypes.data_as(C.c_void_p),
+                                 e.ctypes.data_as(C.c_void_p), C.byref(ne)), self._h)
+        return T, w, np.float32(n.value), wt, e[:ne.value].copy()
+
+    def set_stream(self, raw_stream: int) -> None:
+        check(lib.glc_ctx_set_stream(self._h, C.c_void_p(raw_stream)), self._h)
+
+    def synchronize(self) -> None:
+        check(lib.glc_ctx_synchronize(self._h), self._h)
+
+
+class Encoder(_Ctx):
+    """Encoder::new(sample_rate) — src/codec.rs:406."""
+
+    def __init__(self, sample_rate: int, device: int = 0):
+        super().__init__(sample_rate, device)
+
+    def encode(self, samples, channels: int) -> EncodedAudio:
+        """Encoder::encode(&mut self, samples: &[f32], channels: u16) — src/codec.rs:421."""
+        pcm = np.ascontiguousarray(samples, np.float32).reshape(-1)
+        out = C.c_void_p()
+        check(lib.glc_encode(self._h, pcm.ctypes.data_as(C.c_void_p), pcm.size, channels, C.byref(out)),
+              self._h)
+        return EncodedAudio(out.value)
+
+    def encode_range_device(self, d_pcm: int, t0: int, t_count: int, n_samples: int, channels: int,
+                            frame_begin: int, frame_end: int, d_records: int, d_coeffs: int = 0) -> None:
+        """Device-resident frame range (body of the rayon loop, src/codec.rs:462-541).  Pointers
+        are raw device addresses; work is queued on the context's stream, not synchronised."""
+        check(lib.glc_encode_range_device(self._h, C.c_void_p(d_pcm), t0, t_count, n_samples, channels,
+                                          frame_begin, frame_end, C.c_void_p(d_records),
+                                          C.c_void_p(d_coeffs) if d_coeffs else None), self._h)
+
+    def mdct_forward_device(self, d_pcm: int, t0: int, t_count: int, n_samples: int, channels: int,
+                            frame_begin: int, frame_end: int, d_coeffs: int) -> None:
+        """Window + mdct_block only (src/codec.rs:476-485) for a frame range, device-resident."""
+        check(lib.glc_mdct_forward_device(self._h, C.c_void_p(d_pcm), t0, t_count, n_samples, channels,
+                                          frame_begin, frame_end, C.c_void_p(d_coeffs)), self._h)
+
+
+class Decoder(_Ctx):
+    """Decoder::new(channels, sample_rate) — src/codec.rs:581.  `channels` is accepted and
+    ignored exactly like the reference (quirk Q4): the stream's header decides."""
+
+    def __init__(self, channels: int, sample_rate: int, device: int = 0):
+        super().__init__(sample_rate, device)
+        self.channels = channels
+
+    def decode(self, encoded: EncodedAudio, progress_sender=None) -> np.ndarray:
+        """Decoder::decode — src/codec.rs:744-768 (overlap-add, gapless trim)."""
+        n = lib.glc_decoded_len(encoded._h)
+        out = np.empty(n, np.float32)
+        got = C.c_uint64()
+        check(lib.glc_decode(self._h, encoded._h, out.ctypes.data_as(C.c_void_p), n, C.byref(got)),
+              self._h)
+        return out[:got.value]
+
+    def decode_streaming(self, encoded: EncodedAudio, progress_sender=None) -> Iterator[AudioChunk]:
+        """Decoder::decode_streaming — src/codec.rs:595-741: yields AudioChunk until is_last."""
+        check(lib.glc_decode_stream_begin(self._h, encoded._h), self._h)
+        ch = encoded.header.channels
+        cap = FRAMES_PER_CHUNK * HOP_SIZE * ch  # the last chunk is < 500 frames + the tail hop
+        while True:
+            buf = np.empty(cap, np.float32)
+            n = C.c_uint64()
+            last = C.c_int()
+            check(lib.glc_decode_stream_next(self._h, buf.ctypes.data_as(C.c_void_p), cap, C.byref(n),
+                                             C.byref(last)), self._h)
+            yield AudioChunk(buf[:n.value].copy(), bool(last.value))
+            if last.value:
+                return
+
+
+def save_encoded(encoded: EncodedAudio, path) -> None:
+    """src/codec.rs:774-779"""
+    check(lib.glc_save(encoded._h, str(path).encode()))
+
+
+def load_encoded(path) -> EncodedAudio:
+    """src/codec.rs:781-786"""
+    out = C.c_void_p()
+    check(lib.glc_load(str(path).encode(), C.byref(out)))
+    return EncodedAudio(out.value)

@@ -1,0 +1,381 @@
+// glc_frames.cpp — EncodedAudio on the host: assembly from device records, the .glc container
+// (bincode 1.x default options, as produced by src/codec.rs:774-786) and accessors.
+//
+// Wire format (from the serde derive order of the structs at src/codec.rs:31-69; bincode 1.x:
+// little-endian fixed-width integers, u64 sequence lengths, one-byte Option tag):
+//   u32 sample_rate | u16 channels | u64 total_samples
+//   u64 n_frames, per frame:
+//     u64 n_lists, per list: u64 n_pairs, n_pairs x (u16 index, i16 value)
+//     u64 n_scales, n_scales x f32
+//     u8 tag, if tag == 1: u64 n_raw, n_raw x i16
+//   u32 encoder_delay | u32 padding | u64 original_length
+#include <cstdio>
+#include <memory>
+#include <new>
+
+#include "glc_common.h"
+
+namespace {
+
+struct Writer {
+  uint8_t *p;
+  uint64_t pos = 0;
+  template <class T>
+  void put(T v) {
+    std::memcpy(p + pos, &v, sizeof(T));
+    pos += sizeof(T);
+  }
+  void bytes(const void *src, uint64_t n) {
+    if (n) std::memcpy(p + pos, src, n);
+    pos += n;
+  }
+};
+
+struct Reader {
+  const uint8_t *p;
+  uint64_t len;
+  uint64_t pos = 0;
+  bool ok = true;
+  template <class T>
+  T get() {
+    T v{};
+    if (!ok || len - pos < sizeof(T)) {
+      ok = false;
+      return v;
+    }
+    std::memcpy(&v, p + pos, sizeof(T));
+    pos += sizeof(T);
+    return v;
+  }
+  // sequence length followed by `n * elem` bytes must still fit in the buffer
+  uint64_t seq_len(uint64_t elem) {
+    uint64_t n = get<uint64_t>();
+    if (ok && n > (len - pos) / elem) ok = false;
+    return ok ? n : 0;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+uint64_t glc_record_bytes(uint16_t channels) { return glc::record_bytes(channels); }
+
+int glc_plan_encode(uint64_t n_samples, uint16_t channels, glc_plan *out) {
+  if (!out) return GLC_EINVAL;
+  *out = glc::plan_encode(n_samples, channels);
+  if (out->n_frames == 0) {
+    glc::set_global_error("glc_plan_encode: the reference encoder panics on this input "
+                          "(channels == 0, <= 512 samples per channel, or ragged channels)");
+    return GLC_EINVAL;
+  }
+  return GLC_OK;
+}
+
+int glc_frames_from_records(uint32_t sample_rate, uint64_t n_samples, uint16_t channels,
+                            const void *records, uint64_t n_frames, glc_frames **out) {
+  if (!records || !out) return GLC_EINVAL;
+  const glc_plan plan = glc::plan_encode(n_samples, channels);
+  if (plan.n_frames == 0 || plan.n_frames != n_frames) {
+    glc::set_global_error("glc_frames_from_records: record count does not match the stream length");
+    return GLC_EINVAL;
+  }
+  std::unique_ptr<glc_frames> F(new (std::nothrow) glc_frames);
+  if (!F) return GLC_ENOMEM;
+  const uint32_t ch = channels;
+  const uint64_t rec = glc::record_bytes(ch), hdr = glc::record_header_bytes(ch);
+  F->sample_rate = sample_rate;
+  F->channels = channels;
+  F->total_samples = n_samples;           // src/codec.rs:423,555
+  F->encoder_delay = plan.encoder_delay;  // :547
+  F->padding = plan.padding;              // :546
+  F->original_length = n_samples;         // :562
+  F->n_frames = n_frames;
+  try {
+    F->list_begin.assign(n_frames + 1, 0);
+    F->scale_begin.assign(n_frames + 1, 0);
+    F->raw_begin.assign(n_frames + 1, 0);
+    F->raw_tag.assign(n_frames, 0);
+    // pass 1: sizes
+    uint64_t n_lists = 0, n_pairs = 0, n_scales = 0, n_raw = 0;
+    const uint8_t *base = static_cast<const uint8_t *>(records);
+    for (uint64_t f = 0; f < n_frames; ++f) {
+      const uint8_t *r = base + f * rec;
+      uint32_t is_raw;
+      std::memcpy(&is_raw, r, 4);
+      F->raw_tag[f] = is_raw ? 1 : 0;
+      if (is_raw) {
+        n_raw += static_cast<uint64_t>(glc::kFrame) * ch;  // FRAME_SIZE per channel, :469
+      } else {
+        n_lists += ch;
+        n_scales += ch;
+        for (uint32_t c = 0; c < ch; ++c) {
+          uint32_t nnz;
+          std::memcpy(&nnz, r + 8 + 8 * c + 4, 4);
+          if (nnz > glc::kHop) {
+            glc::set_global_error("glc_frames_from_records: corrupt record (nnz > 1024)");
+            return GLC_EINVAL;
+          }
+          n_pairs += nnz;
+        }
+      }
+      F->list_begin[f + 1] = n_lists;
+      F->scale_begin[f + 1] = n_scales;
+      F->raw_begin[f + 1] = n_raw;
+    }
+    F->list_off.assign(n_lists + 1, 0);
+    F->pairs.resize(n_pairs);
+    F->scales.resize(n_scales);
+    F->raw.resize(n_raw);
+    // pass 2: payload.  Ascending-k scan of the dense row == push order at :285-308.
+    uint64_t li = 0, pi = 0, si = 0, ri = 0;
+    for (uint64_t f = 0; f < n_frames; ++f) {
+      const uint8_t *r = base + f * rec;
+      const int16_t *payload = reinterpret_cast<const int16_t *>(r + hdr);
+      if (F->raw_tag[f]) {
+        std::memcpy(&F->raw[ri], payload, sizeof(int16_t) * glc::kFrame * ch);  // planar, Q1
+        ri += static_cast<uint64_t>(glc::kFrame) * ch;
+        continue;
+      }
+      for (uint32_t c = 0; c < ch; ++c) {
+        float scale;
+        uint32_t nnz;
+        std::memcpy(&scale, r + 8 + 8 * c, 4);
+        std::memcpy(&nnz, r + 8 + 8 * c + 4, 4);
+        F->scales[si++] = scale;
+        const int16_t *row = payload + static_cast<size_t>(c) * glc::kFrame;
+        const uint64_t start = pi;
+        for (uint32_t k = 0; k < glc::kHop && pi - start < nnz; ++k) {
+          const int16_t q = row[k];
+          if (q != 0) F->pairs[pi++] = static_cast<uint32_t>(k) | (static_cast<uint32_t>(static_cast<uint16_t>(q)) << 16);
+        }
+        if (pi - start != nnz) {
+          glc::set_global_error("glc_frames_from_records: corrupt record (nnz mismatch)");
+          return GLC_EINVAL;
+        }
+        F->list_off[++li] = pi;
+      }
+    }
+  } catch (const std::bad_alloc &) {
+    return GLC_ENOMEM;
+  }
+  *out = F.release();
+  return GLC_OK;
+}
+
+uint64_t glc_serialized_size(const glc_frames *f) {
+  if (!f) return 0;
+  uint64_t n = 4 + 2 + 8 + 8;
+  n += f->n_frames * (8 + 8 + 1);
+  n += (f->list_off.size() - 1) * 8;
+  n += f->pairs.size() * 4 + f->scales.size() * 4 + f->raw.size() * 2;
+  for (uint64_t i = 0; i < f->n_frames; ++i) n += f->raw_tag[i] ? 8 : 0;
+  n += 4 + 4 + 8;
+  return n;
+}
+
+int glc_serialize(const glc_frames *f, uint8_t *buf, uint64_t cap, uint64_t *written) {
+  if (!f || !buf) return GLC_EINVAL;
+  const uint64_t need = glc_serialized_size(f);
+  if (cap < need) {
+    glc::set_global_error("glc_serialize: buffer too small");
+    return GLC_EINVAL;
+  }
+  Writer w{buf};
+  w.put<uint32_t>(f->sample_rate);
+  w.put<uint16_t>(f->channels);
+  w.put<uint64_t>(f->total_samples);
+  w.put<uint64_t>(f->n_frames);
+  for (uint64_t i = 0; i < f->n_frames; ++i) {
+    const uint64_t l0 = f->list_begin[i], l1 = f->list_begin[i + 1];
+    w.put<uint64_t>(l1 - l0);
+    for (uint64_t l = l0; l < l1; ++l) {
+      const uint64_t a = f->list_off[l], b = f->list_off[l + 1];
+      w.put<uint64_t>(b - a);
+      w.bytes(f->pairs.data() + a, (b - a) * 4);  // (u16 LE, i16 LE) == packed u32 LE
+    }
+    const uint64_t s0 = f->scale_begin[i], s1 = f->scale_begin[i + 1];
+    w.put<uint64_t>(s1 - s0);
+    w.bytes(f->scales.data() + s0, (s1 - s0) * 4);
+    w.put<uint8_t>(f->raw_tag[i]);
+    if (f->raw_tag[i]) {
+      const uint64_t r0 = f->raw_begin[i], r1 = f->raw_begin[i + 1];
+      w.put<uint64_t>(r1 - r0);
+      w.bytes(f->raw.data() + r0, (r1 - r0) * 2);
+    }
+  }
+  w.put<uint32_t>(f->encoder_delay);
+  w.put<uint32_t>(f->padding);
+  w.put<uint64_t>(f->original_length);
+  if (written) *written = w.pos;
+  return w.pos == need ? GLC_OK : GLC_EFORMAT;
+}
+
+int glc_deserialize(const uint8_t *buf, uint64_t len, glc_frames **out) {
+  if (!buf || !out) return GLC_EINVAL;
+  std::unique_ptr<glc_frames> F(new (std::nothrow) glc_frames);
+  if (!F) return GLC_ENOMEM;
+  Reader r{buf, len};
+  F->sample_rate = r.get<uint32_t>();
+  F->channels = r.get<uint16_t>();
+  F->total_samples = r.get<uint64_t>();
+  const uint64_t nf = r.seq_len(8 + 8 + 1);  // every frame costs at least 17 bytes
+  if (!r.ok) {
+    glc::set_global_error("glc_deserialize: truncated header");
+    return GLC_EFORMAT;
+  }
+  try {
+    F->n_frames = nf;
+    F->list_begin.assign(nf + 1, 0);
+    F->scale_begin.assign(nf + 1, 0);
+    F->raw_begin.assign(nf + 1, 0);
+    F->raw_tag.assign(nf, 0);
+    F->list_off.assign(1, 0);
+    for (uint64_t i = 0; i < nf && r.ok; ++i) {
+      const uint64_t nl = r.seq_len(8);
+      for (uint64_t l = 0; l < nl && r.ok; ++l) {
+        const uint64_t np = r.seq_len(4);
+        if (!r.ok) break;
+        const size_t at = F->pairs.size();
+        F->pairs.resize(at + np);
+        if (np) std::memcpy(F->pairs.data() + at, buf + r.pos, np * 4);
+        r.pos += np * 4;
+        F->list_off.push_back(F->pairs.size());
+      }
+      F->list_begin[i + 1] = F->list_off.size() - 1;
+      const uint64_t ns = r.seq_len(4);
+      if (!r.ok) break;
+      const size_t sat = F->scales.size();
+      F->scales.resize(sat + ns);
+      if (ns) std::memcpy(F->scales.data() + sat, buf + r.pos, ns * 4);
+      r.pos += ns * 4;
+      F->scale_begin[i + 1] = F->scales.size();
+      const uint8_t tag = r.get<uint8_t>();
+      if (tag > 1) r.ok = false;  // bincode rejects any other Option tag
+      if (!r.ok) break;
+      F->raw_tag[i] = tag;
+      if (tag) {
+        const uint64_t nr = r.seq_len(2);
+        if (!r.ok) break;
+        const size_t rat = F->raw.size();
+        F->raw.resize(rat + nr);
+        if (nr) std::memcpy(F->raw.data() + rat, buf + r.pos, nr * 2);
+        r.pos += nr * 2;
+      }
+      F->raw_begin[i + 1] = F->raw.size();
+    }
+    F->encoder_delay = r.get<uint32_t>();
+    F->padding = r.get<uint32_t>();
+    F->original_length = r.get<uint64_t>();
+  } catch (const std::bad_alloc &) {
+    return GLC_ENOMEM;
+  }
+  if (!r.ok) {
+    glc::set_global_error("glc_deserialize: malformed or truncated .glc stream");
+    return GLC_EFORMAT;
+  }
+  // bincode::deserialize (not deserialize_from) ignores trailing bytes; so do we.
+  *out = F.release();
+  return GLC_OK;
+}
+
+int glc_save(const glc_frames *f, const char *path) {
+  if (!f || !path) return GLC_EINVAL;
+  const uint64_t n = glc_serialized_size(f);
+  std::vector<uint8_t> buf(n);
+  uint64_t w = 0;
+  int rc = glc_serialize(f, buf.data(), n, &w);
+  if (rc != GLC_OK) return rc;
+  FILE *fp = std::fopen(path, "wb");
+  if (!fp) {
+    glc::set_global_error(std::string("glc_save: cannot open ") + path);
+    return GLC_EIO;
+  }
+  const size_t put = std::fwrite(buf.data(), 1, w, fp);
+  const int cl = std::fclose(fp);
+  if (put != w || cl != 0) {
+    glc::set_global_error(std::string("glc_save: short write to ") + path);
+    return GLC_EIO;
+  }
+  return GLC_OK;
+}
+
+int glc_load(const char *path, glc_frames **out) {
+  if (!path || !out) return GLC_EINVAL;
+  FILE *fp = std::fopen(path, "rb");
+  if (!fp) {
+    glc::set_global_error(std::string("glc_load: cannot open ") + path);
+    return GLC_EIO;
+  }
+  std::vector<uint8_t> buf;
+  uint8_t tmp[1 << 16];
+  size_t got;
+  while ((got = std::fread(tmp, 1, sizeof tmp, fp)) > 0) buf.insert(buf.end(), tmp, tmp + got);
+  std::fclose(fp);
+  return glc_deserialize(buf.data(), buf.size(), out);
+}
+
+void glc_frames_free(glc_frames *f) { delete f; }
+
+int glc_frames_info(const glc_frames *f, glc_info *out) {
+  if (!f || !out) return GLC_EINVAL;
+  std::memset(out, 0, sizeof *out);
+  out->sample_rate = f->sample_rate;
+  out->channels = f->channels;
+  out->total_samples = f->total_samples;
+  out->encoder_delay = f->encoder_delay;
+  out->padding = f->padding;
+  out->original_length = f->original_length;
+  out->n_frames = f->n_frames;
+  for (uint64_t i = 0; i < f->n_frames; ++i) out->n_raw_frames += f->raw_tag[i];
+  out->total_nnz = f->pairs.size();
+  return GLC_OK;
+}
+
+int glc_frame_is_raw(const glc_frames *f, uint64_t frame) {
+  if (!f || frame >= f->n_frames) return GLC_EINVAL;
+  return f->raw_tag[frame];
+}
+
+int glc_frame_sparse(const glc_frames *f, uint64_t frame, uint32_t channel, uint16_t *idx,
+                     int16_t *q, uint32_t cap, uint32_t *n) {
+  if (!f || frame >= f->n_frames) return GLC_EINVAL;
+  const uint64_t l = f->list_begin[frame] + channel;
+  if (l >= f->list_begin[frame + 1]) return GLC_EINVAL;
+  const uint64_t a = f->list_off[l], b = f->list_off[l + 1];
+  if (n) *n = static_cast<uint32_t>(b - a);
+  for (uint64_t j = a; j < b && j - a < cap; ++j) {
+    if (idx) idx[j - a] = static_cast<uint16_t>(f->pairs[j] & 0xFFFFu);
+    if (q) q[j - a] = static_cast<int16_t>(f->pairs[j] >> 16);
+  }
+  return GLC_OK;
+}
+
+int glc_frame_scale(const glc_frames *f, uint64_t frame, uint32_t channel, float *scale) {
+  if (!f || !scale || frame >= f->n_frames) return GLC_EINVAL;
+  const uint64_t s = f->scale_begin[frame] + channel;
+  if (s >= f->scale_begin[frame + 1]) return GLC_EINVAL;
+  *scale = f->scales[s];
+  return GLC_OK;
+}
+
+int glc_frame_raw(const glc_frames *f, uint64_t frame, int16_t *pcm, uint64_t cap, uint64_t *n) {
+  if (!f || frame >= f->n_frames || !f->raw_tag[frame]) return GLC_EINVAL;
+  const uint64_t a = f->raw_begin[frame], b = f->raw_begin[frame + 1];
+  if (n) *n = b - a;
+  if (pcm) std::memcpy(pcm, f->raw.data() + a, sizeof(int16_t) * ((b - a) < cap ? (b - a) : cap));
+  return GLC_OK;
+}
+
+uint64_t glc_decoded_len(const glc_frames *f) {
+  if (!f) return 0;
+  // src/codec.rs:756-765
+  uint64_t all = (f->n_frames + 1) * static_cast<uint64_t>(glc::kHop) * f->channels;
+  if (all > f->encoder_delay) all -= f->encoder_delay;
+  if (all > f->original_length) all = f->original_length;
+  return all;
+}
+
+const char *glc_version(void) { return "glc-mi355x 0.1 (reference gapless-lossy-codec 0.5.0)"; }
+
+}  // extern "C"

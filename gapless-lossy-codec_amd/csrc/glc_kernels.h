@@ -1,0 +1,63 @@
+// glc_kernels.h — launch interface of the gfx950 kernels (implemented in glc_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace glc {
+
+// Device-resident constant tables of one context.
+struct DeviceTables {
+  const float *cos_t;      // [2048][1024]  T transposed (row i): forward MDCT operand
+  const float *cos;        // [1024][2048]  T (row k): inverse MDCT operand
+  const float *window;     // [2048]
+  const float *indiv;      // [1024] 1/weights[k].max(0.1)
+  const float *band_pf;    // [n_bands]
+  const float *band_len;   // [n_bands]
+  const uint16_t *band_of; // [1024]
+  const uint32_t *edges;   // [n_bands+1]
+  uint32_t n_bands;
+  float norm, cf, noise_floor;
+};
+
+// View of interleaved PCM on the device (whole stream or a shard with halo).
+struct PcmView {
+  const float *p;      // element (t0*ch) of the stream
+  uint64_t t0;         // first per-channel sample index present
+  uint64_t t_count;    // per-channel samples present
+  uint64_t n_samples;  // interleaved length of the WHOLE stream
+  uint32_t ch;
+};
+
+// K1: windowed forward MDCT of rows [0, M) (row = (frame - frame_begin)*ch + c) -> coef[M][1024].
+hipError_t launch_mdct_forward(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin,
+                               uint32_t M, float *coef, hipStream_t s);
+// K2: scale, masking thresholds, quantiser -> record header {scale,nnz} + dense i16 row.
+hipError_t launch_quantize(const DeviceTables &t, const float *coef, uint32_t M, uint32_t ch,
+                           uint8_t *records, hipStream_t s);
+// K3: per-frame raw-vs-compressed decision and raw fallback plane.
+hipError_t launch_decide_raw(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin,
+                             uint32_t n_frames, uint8_t *records, hipStream_t s);
+
+// D1: sparse dequant + inverse MDCT + window -> blocks[row][2048].
+//   pairs: packed (u16 idx | i16 q << 16), canonical (ascending, unique, idx < 1024)
+//   row_off[M+1]: pair ranges; row_scale[M]; row_raw[M]: -1 or offset (in i16) of the frame's
+//   raw_pcm vec in raw_pool, row_raw_len[M] its length, row_ch[M] channel index.
+struct DecodeRows {
+  const uint32_t *pairs;
+  const uint64_t *row_off;
+  const float *row_scale;
+  const int64_t *row_raw;
+  const uint64_t *row_raw_len;
+  const int16_t *raw_pool;
+};
+hipError_t launch_imdct_rows(const DeviceTables &t, const DecodeRows &rows, uint32_t row_begin,
+                             uint32_t M, uint32_t ch, float *blocks, hipStream_t s);
+// D2: overlap-add + interleave of hops [hop_begin, hop_end) into out (hop h = second half of
+// frame h-1 + first half of frame h; hop n_frames is the bare overlap tail).  `blocks` holds
+// frames blk_frame0, blk_frame0+1, ... (blk_frame0 may be -1: a zero "frame before the first").
+hipError_t launch_overlap_add(const float *blocks, int64_t blk_frame0, uint64_t n_frames,
+                              uint32_t ch, uint64_t hop_begin, uint64_t hop_end, float *out,
+                              hipStream_t s);
+
+}  // namespace glc

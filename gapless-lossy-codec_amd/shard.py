@@ -1,0 +1,81 @@
+"""Frame-range sharding of one encode across ranks, and the single gather that ends it.
+
+Frames are independent (the rayon loop at src/codec.rs:462): rank r encodes the contiguous frame
+range [f0_r, f1_r) from the slice of interleaved PCM that range reads — per-channel samples
+[1024*f0 - 512, 1024*f1 + 512) clipped to the stream, i.e. the range plus a halo shared with its
+neighbours, supplied at upload time (no device exchange).  Every rank emits fixed-size frame
+records; ONE gather of those records to rank 0 is the only collective (RCCL over xGMI when the
+process group is `nccl`, gloo in the CPU tests).  Rank 0 assembles EncodedAudio from the
+concatenated records with glc_frames_from_records.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+HOP = 1024
+FRAME = 2048
+
+
+@dataclass(frozen=True)
+class Shard:
+    rank: int
+    frame_begin: int
+    frame_end: int
+    t0: int        # first per-channel sample index the shard holds
+    t_count: int   # per-channel samples the shard holds
+
+    @property
+    def n_frames(self) -> int:
+        return self.frame_end - self.frame_begin
+
+
+def frame_ranges(n_frames: int, world: int) -> List[range]:
+    """Contiguous, balanced partition: the first n_frames % world ranks get one extra frame."""
+    base, extra = divmod(n_frames, world)
+    out, f = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append(range(f, f + n))
+        f += n
+    return out
+
+
+def plan_shards(n_frames: int, per_channel: int, world: int) -> List[Shard]:
+    """Shard r = frames + the PCM span (with halo) they read, clipped to [0, per_channel)."""
+    shards = []
+    for r, fr in enumerate(frame_ranges(n_frames, world)):
+        if len(fr) == 0:
+            shards.append(Shard(r, fr.start, fr.stop, 0, 0))
+            continue
+        lo = max(0, fr.start * HOP - HOP // 2)
+        hi = min(per_channel, (fr.stop - 1) * HOP - HOP // 2 + FRAME)
+        hi = max(hi, lo)
+        shards.append(Shard(r, fr.start, fr.stop, lo, hi - lo))
+    return shards
+
+
+def gather_records(local_records, shards: List[Shard], record_bytes: int, group=None, dst: int = 0):
+    """The single collective: gather every rank's record bytes (a flat uint8 torch tensor, on
+    the GPU for nccl / on the CPU for gloo) to `dst`.  Shards may differ by one frame, so every
+    rank pads to the largest shard; `dst` strips the padding and returns the records of all
+    frames in frame order as one flat tensor (None on other ranks)."""
+    import torch
+    import torch.distributed as dist
+
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    assert world == len(shards)
+    max_bytes = max(s.n_frames for s in shards) * record_bytes
+    send = local_records.reshape(-1)
+    assert send.dtype == torch.uint8 and send.numel() == shards[rank].n_frames * record_bytes
+    if send.numel() < max_bytes:
+        pad = torch.zeros(max_bytes - send.numel(), dtype=torch.uint8, device=send.device)
+        send = torch.cat([send, pad])
+    recv: Optional[list] = None
+    if rank == dst:
+        recv = [torch.empty(max_bytes, dtype=torch.uint8, device=send.device) for _ in range(world)]
+    dist.gather(send, recv, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([recv[r][: shards[r].n_frames * record_bytes] for r in range(world)])

@@ -1,0 +1,189 @@
+/*
+ * glc.h — C ABI of the MI355X-native MDCT / quantiser hot path of the gapless lossy codec.
+ *
+ * Drop-in boundary for the reference crate `gapless_lossy_codec` (v0.5.0).  The reference has no
+ * FFI seam today: `Encoder` / `Decoder` are concrete Rust structs in src/codec.rs.  Each entry
+ * point below names the reference item it replaces (file:line into the reference tree); a thin
+ * Rust shim keeps the Rust signatures and forwards here.
+ *
+ * Conventions
+ *   - plain pointers and sizes, no C++/torch types; all integers little-endian host order
+ *   - return 0 (GLC_OK) on success, a negative glc_status otherwise; the text of the last
+ *     failure is available from glc_last_error()
+ *   - a glc_ctx is NOT thread-safe (≙ `&mut self`, src/codec.rs:421,744); distinct contexts may
+ *     be used from distinct threads
+ *   - inputs the reference would panic on (channels == 0, <= 512 samples per
+ *     channel, ragged channel lengths that under-run a frame) return GLC_EINVAL instead
+ *   - there is NO CPU fallback: every compute entry point fails with GLC_ENODEV / GLC_EHIP when
+ *     no gfx950 device is usable
+ */
+#ifndef GLC_H
+#define GLC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLC_FRAME_SIZE 2048u /* src/codec.rs:15 FRAME_SIZE */
+#define GLC_HOP_SIZE 1024u   /* src/codec.rs:16 HOP_SIZE  */
+#define GLC_FRAMES_PER_CHUNK 500u /* src/codec.rs:18 */
+
+typedef enum glc_status {
+  GLC_OK = 0,
+  GLC_EINVAL = -1,  /* bad argument / input the reference panics on */
+  GLC_EHIP = -2,    /* HIP runtime or kernel failure */
+  GLC_ENOMEM = -3,  /* host or device allocation failed */
+  GLC_EFORMAT = -4, /* malformed .glc byte stream (bincode error in load_encoded) */
+  GLC_ENODEV = -5,  /* no usable gfx950 device */
+  GLC_EIO = -6      /* file I/O error (save_encoded / load_encoded) */
+} glc_status;
+
+/* ≙ Encoder / Decoder (src/codec.rs:396-402, :571-577): MDCT table, window, perceptual model,
+ * device workspaces and the HIP stream the kernels run on. */
+typedef struct glc_ctx glc_ctx;
+/* ≙ EncodedAudio (src/codec.rs:31-37), owned by the library. */
+typedef struct glc_frames glc_frames;
+
+/* ≙ AudioHeader + GaplessInfo (src/codec.rs:39-53) + summary counts. */
+typedef struct glc_info {
+  uint32_t sample_rate;
+  uint16_t channels;
+  uint16_t reserved;
+  uint64_t total_samples;
+  uint32_t encoder_delay;
+  uint32_t padding;
+  uint64_t original_length;
+  uint64_t n_frames;
+  uint64_t n_raw_frames; /* frames carrying raw_pcm: Some(..) */
+  uint64_t total_nnz;    /* sum of sparse list lengths */
+} glc_info;
+
+/* Result of the padding arithmetic of Encoder::encode (src/codec.rs:433-455, :543-547). */
+typedef struct glc_plan {
+  uint64_t n_frames;     /* 0 if the reference would panic */
+  uint64_t padded_len;   /* per-channel length of padded[0] */
+  uint64_t per_channel;  /* per_chan[0].len() */
+  uint32_t encoder_delay;
+  uint32_t padding;
+} glc_plan;
+
+/* ---- context -------------------------------------------------------------------------- */
+
+/* Encoder::new(sample_rate) src/codec.rs:406-418 and Decoder::new(_, sample_rate) :581-592.
+ * Builds MdctTables (:326-356) and PerceptualWeights (:102-183) on the host with the system
+ * libm, uploads them to HIP device `device`, creates the stream and workspaces. */
+int glc_ctx_create(int device, uint32_t sample_rate, glc_ctx **out);
+void glc_ctx_destroy(glc_ctx *ctx);
+/* Message of the last failure on `ctx` (or of the last context-less failure if ctx == NULL). */
+const char *glc_last_error(const glc_ctx *ctx);
+/* The HIP stream (hipStream_t) every kernel of this context is launched on. */
+void *glc_ctx_stream(glc_ctx *ctx);
+int glc_ctx_device(const glc_ctx *ctx);
+/* Run this context's kernels on a caller-owned hipStream_t instead (e.g. the stream a host
+ * framework times with its own events).  The caller keeps ownership; NULL restores the
+ * context's private stream. */
+int glc_ctx_set_stream(glc_ctx *ctx, void *hip_stream);
+/* Block until all work queued on the context's stream has finished. */
+int glc_ctx_synchronize(glc_ctx *ctx);
+
+/* ---- encode --------------------------------------------------------------------------- */
+
+/* Padding / frame-count arithmetic only (host, no device): src/codec.rs:433-455. */
+int glc_plan_encode(uint64_t n_samples, uint16_t channels, glc_plan *out);
+
+/* Encoder::encode(&mut self, samples: &[f32], channels: u16) -> Result<EncodedAudio>
+ * src/codec.rs:421-565.  `pcm` is interleaved host memory, borrowed for the call. */
+int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t channels,
+               glc_frames **out);
+
+/* Fixed-size per-frame record the device path emits (one per frame):
+ *   u32 is_raw, u32 reserved, then per channel {f32 scale, u32 nnz}, padded to 16 B,
+ *   then int16 payload[channels][2048]: compressed frames hold the dense quantised row in
+ *   payload[c][0..1023]; raw frames hold the channel-planar windowed i16 block (Q1). */
+uint64_t glc_record_bytes(uint16_t channels);
+
+/* Device-resident frame-range encode: the body of the rayon loop at src/codec.rs:462-541 for
+ * frames [frame_begin, frame_end) of a stream of `n_samples` interleaved samples.
+ *   d_pcm      device pointer to interleaved f32 PCM covering per-channel sample indices
+ *              [t0, t0 + t_count) of the stream (a shard with its halo, or the whole stream
+ *              with t0 = 0); samples outside the stream are the encoder's zero padding
+ *   d_records  device buffer of (frame_end - frame_begin) * glc_record_bytes(channels) bytes
+ *   d_coeffs   optional device buffer [(frame_end-frame_begin)*channels][1024] f32 receiving
+ *              the MDCT coefficients (parity tap); NULL to use the context workspace
+ * Work is queued on glc_ctx_stream(ctx) and NOT synchronised. */
+int glc_encode_range_device(glc_ctx *ctx, const float *d_pcm, uint64_t t0, uint64_t t_count,
+                            uint64_t n_samples, uint16_t channels, uint64_t frame_begin,
+                            uint64_t frame_end, void *d_records, float *d_coeffs);
+
+/* The transform alone: window (src/codec.rs:476-481) + MdctTables::mdct_block (:359-374) for every
+ * frame-channel of [frame_begin, frame_end) -> d_coeffs[(frame-frame_begin)*channels + c][1024].
+ * Same arguments as glc_encode_range_device; used for kernel-level timing and the parity tap. */
+int glc_mdct_forward_device(glc_ctx *ctx, const float *d_pcm, uint64_t t0, uint64_t t_count,
+                            uint64_t n_samples, uint16_t channels, uint64_t frame_begin,
+                            uint64_t frame_end, float *d_coeffs);
+
+/* Host assembly of EncodedAudio from `n_frames` consecutive records (all shards concatenated in
+ * frame order): builds the sparse (u16, i16) lists in ascending k (src/codec.rs:303-306) and the
+ * header / gapless info (:543-564). */
+int glc_frames_from_records(uint32_t sample_rate, uint64_t n_samples, uint16_t channels,
+                            const void *records, uint64_t n_frames, glc_frames **out);
+
+/* ---- decode --------------------------------------------------------------------------- */
+
+/* Length Decoder::decode will return: min(original_length, (n_frames+1)*1024*ch - delay). */
+uint64_t glc_decoded_len(const glc_frames *in);
+
+/* Decoder::decode(&mut self, &EncodedAudio, _) -> Result<Vec<f32>>  src/codec.rs:744-768
+ * (including decode_streaming :595-741, overlap-add and the gapless trim). */
+int glc_decode(glc_ctx *ctx, const glc_frames *in, float *pcm_out, uint64_t cap,
+               uint64_t *n_out);
+
+/* Decoder::decode_streaming src/codec.rs:595-741: un-trimmed output delivered in chunks of at
+ * least FRAMES_PER_CHUNK*1024*channels samples (AudioChunk, :81-85).  `begin` decodes on the
+ * device; `next` copies the next chunk (returns its size through n_out, sets *is_last on the
+ * final chunk, which carries the overlap tail :722-732). */
+int glc_decode_stream_begin(glc_ctx *ctx, const glc_frames *in);
+int glc_decode_stream_next(glc_ctx *ctx, float *chunk, uint64_t cap, uint64_t *n_out,
+                           int *is_last);
+
+/* ---- container (.glc = bincode 1.x of EncodedAudio) ------------------------------------- */
+
+/* save_encoded / load_encoded src/codec.rs:774-786. */
+uint64_t glc_serialized_size(const glc_frames *f);
+int glc_serialize(const glc_frames *f, uint8_t *buf, uint64_t cap, uint64_t *written);
+int glc_deserialize(const uint8_t *buf, uint64_t len, glc_frames **out);
+int glc_save(const glc_frames *f, const char *path);
+int glc_load(const char *path, glc_frames **out);
+void glc_frames_free(glc_frames *f);
+
+/* ---- EncodedAudio accessors ----------------------------------------------------------- */
+
+int glc_frames_info(const glc_frames *f, glc_info *out);
+/* EncodedFrame.raw_pcm.is_some() */
+int glc_frame_is_raw(const glc_frames *f, uint64_t frame);
+/* EncodedFrame.sparse_coeffs_per_channel[channel]: copies up to cap pairs, returns the list
+ * length through n (idx/q may be NULL to query). */
+int glc_frame_sparse(const glc_frames *f, uint64_t frame, uint32_t channel, uint16_t *idx,
+                     int16_t *q, uint32_t cap, uint32_t *n);
+/* EncodedFrame.scale_factors[channel] */
+int glc_frame_scale(const glc_frames *f, uint64_t frame, uint32_t channel, float *scale);
+/* EncodedFrame.raw_pcm: copies up to cap samples, returns the length through n. */
+int glc_frame_raw(const glc_frames *f, uint64_t frame, int16_t *pcm, uint64_t cap, uint64_t *n);
+
+/* ---- tables (for inspection / parity tests) ---------------------------------------------- */
+
+/* Copies of the host tables of a context: MdctTables.cos_table [1024*2048] (row k), window
+ * [2048], norm; PerceptualWeights.weights [1024] and critical_bands (<= 51 edges).
+ * Any pointer may be NULL. */
+int glc_ctx_tables(const glc_ctx *ctx, float *cos_table, float *window, float *norm,
+                   float *weights, uint32_t *band_edges, uint32_t *n_edges);
+
+const char *glc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLC_H */

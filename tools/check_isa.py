@@ -1,0 +1,55 @@
+"""Build-time guard of the numerics contract: the transform kernels must not contain a fused
+multiply-add (v_fma*, v_fmac*, v_pk_fma*, v_mad*, v_mac*, v_dot*) or an accumulating MFMA — the
+reference accumulates with a separately rounded multiply and add.
+
+  k_mdct_fwd    strict: no fused op at all (it contains no division or sqrt)
+  k_imdct_rows  fused ops allowed only inside hipcc's correctly-rounded f32 division expansion
+                (v_div_scale ... v_div_fixup), which the raw-frame path `i16 / 32767.0` needs
+The quantiser / decision / overlap-add kernels are not scanned: their IEEE divide, sqrt and
+64-bit index division expand to FMA-based sequences by design; their arithmetic is pinned by the
+bit-exact parity tests instead."""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "gapless-lossy-codec_amd", "csrc")
+ISA = os.path.join(ROOT, "build", "isa", "glc_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")
+FORBIDDEN = re.compile(r"^\s+(v_fma\w*|v_fmac\w*|v_pk_fma\w*|v_mad_\w*f32|v_mac\w*|v_dot\w*|v_mfma\w*)\b")
+KERNELS = ("k_mdct_fwd", "k_imdct_rows")
+DIV_WINDOW = {"k_imdct_rows"}
+
+
+def main() -> int:
+    subprocess.check_call(["make", "-C", CSRC, "-s", "isa"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    cur, bad, seen, in_div = None, [], set(), False
+    for line in open(ISA):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = next((k for k in KERNELS if k in m.group(1)), None)
+            in_div = False
+            if cur:
+                seen.add(cur)
+        elif cur and cur in DIV_WINDOW and "v_div_scale_f32" in line:
+            in_div = True
+        elif cur and "v_div_fixup_f32" in line:
+            in_div = False
+        elif cur and FORBIDDEN.match(line) and not in_div:
+            bad.append((cur, line.strip()))
+        if "s_endpgm" in line:
+            cur = None
+    missing = set(KERNELS) - seen
+    if missing:
+        print("check_isa: kernels not found in ISA:", sorted(missing))
+        return 1
+    if bad:
+        for k, l in bad:
+            print(f"check_isa: fused op in {k}: {l}")
+        return 1
+    print(f"check_isa: {len(seen)} kernels clean (no fused multiply-add)")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
