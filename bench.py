@@ -86,9 +86,7 @@ def main():
     rec_bytes = glc_amd.lib.glc_record_bytes(CH)
     d_rec = torch.empty(me.n_frames * rec_bytes, dtype=torch.uint8, device="cuda")
     d_coef = torch.empty((me.n_frames * CH, 1024), dtype=torch.float32, device="cuda")
-    stream = torch.cuda.Stream()
-    enc = glc_amd.Encoder(SR, device=local_rank)
-    enc.set_stream(stream.cuda_stream)   # kernels and events share this stream
+    enc = glc_amd.Encoder(SR, device=local_rank)  # owns the HIP stream its kernels run on
     torch.cuda.synchronize()
 
     def step():
@@ -99,6 +97,7 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        enc.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -106,6 +105,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    enc.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -119,25 +119,20 @@ def main():
 
     # ---- dominant kernel (K1, forward MDCT) timed alone with events on ITS stream -------
     k1_reps = max(10, min(args.steps, 50))
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    with torch.cuda.stream(stream):
+
+    def k1():
         enc.mdct_forward_device(d_pcm.data_ptr(), me.t0, me.t_count, n_samples, CH, me.frame_begin,
                                 me.frame_end, d_coef.data_ptr())
-        ev0.record()
-        for _ in range(k1_reps):
-            enc.mdct_forward_device(d_pcm.data_ptr(), me.t0, me.t_count, n_samples, CH,
-                                    me.frame_begin, me.frame_end, d_coef.data_ptr())
-        ev1.record()
-    torch.cuda.synchronize()
-    k1_ms = ev0.elapsed_time(ev1) / k1_reps
-    # whole step with events too (for the profile cross-check)
-    with torch.cuda.stream(stream):
-        ev0.record()
-        for _ in range(k1_reps):
-            step()
-        ev1.record()
-    torch.cuda.synchronize()
-    step_ev_ms = ev0.elapsed_time(ev1) / k1_reps
+
+    k1()
+    enc.timer_begin()          # HIP events on the stream the kernels are launched on
+    for _ in range(k1_reps):
+        k1()
+    k1_ms = enc.timer_end() / k1_reps
+    enc.timer_begin()          # whole step with events too (profile cross-check)
+    for _ in range(k1_reps):
+        step()
+    step_ev_ms = enc.timer_end() / k1_reps
 
     samples_per_launch = FRAMES_PER_GPU * HOP * CH  # per GPU
     k1_tflops = samples_per_launch * FLOP_PER_SAMPLE / (k1_ms * 1e-3) / 1e12
@@ -169,8 +164,8 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O  # checker/baseline only — never on the product path
-        cores = os.cpu_count() or 1
-        nfr = FRAMES_PER_GPU  # the full cfg2 batch: ~12 core-seconds
+        cores = min(16, os.cpu_count() or 1)  # a one-GPU box's CPU share is 16 cores
+        nfr = FRAMES_PER_GPU  # the full cfg2 batch: ~12 core-seconds of CPU work
         sec = O.time_encode_frames(pcm_host, SR, CH, 0, nfr, n_threads=cores)
         cpu = {"value": round(nfr * HOP * CH / sec / 1e6, 3), "unit": "Msamples/s", "cores": cores,
                "kind": "port",

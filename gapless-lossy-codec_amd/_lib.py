@@ -47,6 +47,8 @@ SIGNATURES = {
     "glc_ctx_device": (C.c_int, [_vp]),
     "glc_ctx_set_stream": (C.c_int, [_vp, _vp]),
     "glc_ctx_synchronize": (C.c_int, [_vp]),
+    "glc_ctx_timer_begin": (C.c_int, [_vp]),
+    "glc_ctx_timer_end": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "glc_plan_encode": (C.c_int, [C.c_uint64, C.c_uint16, C.POINTER(GlcPlan)]),
     "glc_encode": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint16, C.POINTER(_vp)]),
     "glc_record_bytes": (C.c_uint64, [C.c_uint16]),
@@ -82,6 +84,17 @@ if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
         "(or `make -C gapless-lossy-codec_amd/csrc`).  There is no CPU fallback.")
+
+# PyTorch's ROCm wheel bundles its own HIP + HSA runtimes.  If torch is going to live in this
+# process it must be loaded BEFORE libglc_hip.so (which links the system ROCm): the system
+# libamdhip64 then binds to the HSA runtime torch already loaded (same SONAME) and both HIP
+# runtimes share one device context.  The other order creates two HSA runtimes and the second
+# one to initialise sees no device.  Handles (streams, events) never cross between the two HIP
+# runtimes: the context owns its stream and timer; only raw device addresses are exchanged.
+try:  # torch is plumbing (device memory, torch.distributed), not a dependency of the codec
+    import torch as _torch  # noqa: F401
+except Exception:  # pragma: no cover - torch absent: the system ROCm runtime alone is fine
+    _torch = None
 
 lib = C.CDLL(LIB_PATH)
 for _name, (_res, _args) in SIGNATURES.items():

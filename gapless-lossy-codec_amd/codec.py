@@ -203,6 +203,16 @@ class _Ctx:
     def synchronize(self) -> None:
         check(lib.glc_ctx_synchronize(self._h), self._h)
 
+    def timer_begin(self) -> None:
+        """Record a HIP event on the context's stream (device-side stopwatch)."""
+        check(lib.glc_ctx_timer_begin(self._h), self._h)
+
+    def timer_end(self) -> float:
+        """Record a second event, wait for it, return elapsed milliseconds."""
+        ms = C.c_float()
+        check(lib.glc_ctx_timer_end(self._h, C.byref(ms)), self._h)
+        return ms.value
+
 
 class Encoder(_Ctx):
     """Encoder::new(sample_rate) — src/codec.rs:406."""

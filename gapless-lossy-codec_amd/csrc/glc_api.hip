@@ -54,6 +54,7 @@ struct glc_ctx {
   uint32_t sample_rate = 0;
   hipStream_t stream = nullptr;      // stream in use
   hipStream_t own_stream = nullptr;  // the context's private stream
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;  // glc_ctx_timer_*
   glc::HostTables host;
   glc::DeviceTables dev{};
   DevBuf tables;     // all constant tables in one allocation
@@ -214,6 +215,8 @@ void glc_ctx_destroy(glc_ctx *ctx) {
   if (!ctx) return;
   DeviceGuard guard(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+  if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   ctx->tables.release();
   ctx->coef.release();
@@ -239,6 +242,24 @@ int glc_ctx_synchronize(glc_ctx *ctx) {
   if (!ctx) return GLC_EINVAL;
   DeviceGuard guard(ctx->device);
   GLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GLC_OK;
+}
+
+int glc_ctx_timer_begin(glc_ctx *ctx) {
+  if (!ctx) return GLC_EINVAL;
+  DeviceGuard guard(ctx->device);
+  if (!ctx->ev_begin) GLC_HIP(ctx, hipEventCreate(&ctx->ev_begin));
+  if (!ctx->ev_end) GLC_HIP(ctx, hipEventCreate(&ctx->ev_end));
+  GLC_HIP(ctx, hipEventRecord(ctx->ev_begin, ctx->stream));
+  return GLC_OK;
+}
+
+int glc_ctx_timer_end(glc_ctx *ctx, float *elapsed_ms) {
+  if (!ctx || !elapsed_ms || !ctx->ev_begin) return fail(ctx, GLC_EINVAL, "glc_ctx_timer_end: no timer running");
+  DeviceGuard guard(ctx->device);
+  GLC_HIP(ctx, hipEventRecord(ctx->ev_end, ctx->stream));
+  GLC_HIP(ctx, hipEventSynchronize(ctx->ev_end));
+  GLC_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev_begin, ctx->ev_end));
   return GLC_OK;
 }
 

@@ -88,6 +88,11 @@ int glc_ctx_device(const glc_ctx *ctx);
 int glc_ctx_set_stream(glc_ctx *ctx, void *hip_stream);
 /* Block until all work queued on the context's stream has finished. */
 int glc_ctx_synchronize(glc_ctx *ctx);
+/* Device-side stopwatch on the context's stream: `begin` records a hipEvent, `end` records a
+ * second one, waits for it and returns the elapsed milliseconds between the two — the time the
+ * kernels queued in between spent on that stream. */
+int glc_ctx_timer_begin(glc_ctx *ctx);
+int glc_ctx_timer_end(glc_ctx *ctx, float *elapsed_ms);
 
 /* ---- encode --------------------------------------------------------------------------- */
 
