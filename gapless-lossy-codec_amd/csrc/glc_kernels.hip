@@ -14,6 +14,7 @@
 //   D1 k_imdct_rows    :626-644 (raw frames), :651-665 (dequant), :377-390 (imdct), :672-675
 //   D2 k_overlap_add   :688-705 (overlap-add + interleave), :722-729 (tail)
 #include "glc_kernels.h"
+#include "glc_mdct_fwd.hpp"
 
 #pragma clang fp contract(off)
 
@@ -45,149 +46,7 @@ __device__ __forceinline__ short sat_i16(float x) {
   return static_cast<short>(static_cast<int>(x));
 }
 
-// ------------------------------------------------------------------------------------------
-// K1: C[m][k] = fl( fl( sum_{i ascending} fl( fl(x[m,i]*w[i]) * T[k][i] ) ) * norm )
-//
-// Exact-order SGEMM on the vector ALU: M = frame-channels, N = 1024, K = 2048, no split-K, one
-// accumulator per output, multiply and add issued as separate instructions.  128x128 tile per
-// 256-thread workgroup, 8x8 outputs per lane (as 2x2 groups of 4 so that every LDS read is a
-// conflict-free ds_read_b128), A tile built on the fly from interleaved PCM (window applied
-// while staging), T streamed from L2 through a double-buffered LDS ring.  blockIdx.x % 8 selects
-// the coefficient tile so each XCD's L2 keeps one 1 MiB panel of T.
-// ------------------------------------------------------------------------------------------
-constexpr int BM = 128, BN = 128, BK = 16;
-
-__global__ __launch_bounds__(256, 2) void k_mdct_fwd(DeviceTables tb, PcmView pcm,
-                                                      long long frame_begin, unsigned M,
-                                                      float *__restrict__ coef) {
-  // i-major tiles: As[ii][row], Bs[ii][col]; every ds_read in the inner loop is a b128 whose
-  // 16 lanes of a group cover one contiguous 256-B span (conflict-free).
-  __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
-
-  const int tid = threadIdx.x;
-  const int n_tile = blockIdx.x & 7;  // 1024 / BN = 8 coefficient tiles
-  const int m_tile = blockIdx.x >> 3;
-  const int m0 = m_tile * BM;
-  const int n0 = n_tile * BN;
-  const int tx = tid & 15, ty = tid >> 4;
-
-  // --- A operand: interleaved PCM read through a buffer descriptor whose hardware range check
-  // supplies the encoder's zero padding (512 leading zeros, tail, shard edges): an element
-  // before the descriptor base wraps to a huge unsigned offset, one past the end is >= the
-  // record count; both load 0.0.  All descriptor inputs are blockIdx/kernarg scalars.
-  const long long ch = pcm.ch;
-  const long long f0 = frame_begin + m0 / pcm.ch;                        // first frame of the tile
-  const long long e_first = (f0 * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * ch;
-  long long e_end = static_cast<long long>(pcm.t_count) * ch;            // shard end (elements)
-  const long long n_rel = static_cast<long long>(pcm.n_samples) - static_cast<long long>(pcm.t0) * ch;
-  if (e_end > n_rel) e_end = n_rel;                                      // stream end
-  long long e_base = e_first < 0 ? 0 : e_first;
-  long long e_cnt = e_end - e_base;
-  if (e_cnt < 0) e_cnt = 0;
-  if (e_cnt > (1ll << 28)) e_cnt = 1ll << 28;
-  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float *>(pcm.p + e_base), 0, static_cast<int>(e_cnt * 4), 0x00020000);
-
-  // this thread stages ONE row (r = tid % 128) and 8 of the 16 i of a stage (i = a_i + 2 j)
-  const int a_r = tid & (BM - 1);
-  const int a_i = tid >> 7;
-  const unsigned a_row = m0 + a_r;
-  unsigned a_off = 0x80000000u;  // out-of-range row: every load returns 0
-  if (a_row < M) {
-    const long long f = frame_begin + a_row / pcm.ch;
-    const long long c = a_row % pcm.ch;
-    const long long e_row = (f * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * ch + c;
-    a_off = static_cast<unsigned>((e_row - e_base + a_i * ch) * 4);  // may wrap: that IS the padding
-  }
-  const unsigned a_step = static_cast<unsigned>(2 * ch * 4);  // bytes between this thread's i's
-  const float *w_ptr = tb.window + a_i;
-  // B operand: float4 (row = idx/32, col4 = idx%32), idx = tid + 256 j, j = 0..1
-  const float *b_ptr = tb.cos_t + n0 + static_cast<size_t>(tid >> 5) * kHopI + (tid & 31) * 4;
-
-  float a_stage[8];
-  float4 b_stage[2];
-
-  auto load_stage = [&](int i0) {
-    const unsigned off0 = a_off + static_cast<unsigned>(i0) * static_cast<unsigned>(ch * 4);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float x = __builtin_bit_cast(
-          float, __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, off0 + j * a_step, 0, 0));
-      a_stage[j] = mul_rn(x, w_ptr[i0 + 2 * j]);  // block[i] = slice[i] * window[i], src/codec.rs:480
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      b_stage[j] = *reinterpret_cast<const float4 *>(b_ptr + static_cast<size_t>(i0 + 8 * j) * kHopI);
-  };
-  auto store_stage = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) As[buf][(a_i + 2 * j) * BM + a_r] = a_stage[j];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      *reinterpret_cast<float4 *>(&Bs[buf][((tid >> 5) + 8 * j) * BN + (tid & 31) * 4]) = b_stage[j];
-  };
-
-  float acc[8][8];
-#pragma unroll
-  for (int r = 0; r < 8; ++r)
-#pragma unroll
-    for (int c = 0; c < 8; ++c) acc[r][c] = 0.0f;  // `let mut s = 0.0f32`, :365
-
-  load_stage(0);
-  store_stage(0);
-  __syncthreads();
-
-  constexpr int kStages = kFrameI / BK;
-#pragma unroll 1
-  for (int s = 0; s < kStages; ++s) {
-    const int buf = s & 1;
-    // prefetch the next stage into registers (the last iteration re-fetches stage 0 into the
-    // idle buffer: keeps the loop body branch-free)
-    load_stage(((s + 1) & (kStages - 1)) * BK);
-
-    const float *Ab = As[buf] + ty * 4;
-    const float *Bb = Bs[buf] + tx * 4;
-    float4 a0 = *reinterpret_cast<const float4 *>(&Ab[0]);
-    float4 a1 = *reinterpret_cast<const float4 *>(&Ab[64]);
-    float4 b0 = *reinterpret_cast<const float4 *>(&Bb[0]);
-    float4 b1 = *reinterpret_cast<const float4 *>(&Bb[64]);
-#pragma unroll 2
-    for (int ii = 0; ii < BK; ++ii) {
-      // next i-step's operands in flight while this one computes (the last step re-reads row 0)
-      const int nx = (ii + 1) & (BK - 1);
-      const float4 na0 = *reinterpret_cast<const float4 *>(&Ab[nx * BM]);
-      const float4 na1 = *reinterpret_cast<const float4 *>(&Ab[nx * BM + 64]);
-      const float4 nb0 = *reinterpret_cast<const float4 *>(&Bb[nx * BN]);
-      const float4 nb1 = *reinterpret_cast<const float4 *>(&Bb[nx * BN + 64]);
-      const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-      const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-      for (int r = 0; r < 8; ++r)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[r][c] = add_rn(acc[r][c], mul_rn(av[r], bv[c]));  // :369
-      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
-    }
-
-    store_stage(buf ^ 1);
-    __syncthreads();
-  }
-
-  // epilogue: out[k] = s * norm, :372
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    const unsigned row = m0 + ((r < 4) ? (ty * 4 + r) : (64 + ty * 4 + (r - 4)));
-    if (row >= M) continue;
-    float *dst = coef + static_cast<size_t>(row) * kHopI + n0;
-    float4 o0, o1;
-    o0.x = mul_rn(acc[r][0], tb.norm); o0.y = mul_rn(acc[r][1], tb.norm);
-    o0.z = mul_rn(acc[r][2], tb.norm); o0.w = mul_rn(acc[r][3], tb.norm);
-    o1.x = mul_rn(acc[r][4], tb.norm); o1.y = mul_rn(acc[r][5], tb.norm);
-    o1.z = mul_rn(acc[r][6], tb.norm); o1.w = mul_rn(acc[r][7], tb.norm);
-    *reinterpret_cast<float4 *>(dst + tx * 4) = o0;
-    *reinterpret_cast<float4 *>(dst + 64 + tx * 4) = o1;
-  }
-}
+// K1 (forward MDCT) lives in glc_mdct_fwd.hpp.
 
 // ------------------------------------------------------------------------------------------
 // K2: one wavefront per frame-channel row.  scale = max|c| (order-free), per-band sequential
@@ -411,11 +270,12 @@ __global__ __launch_bounds__(256) void k_overlap_add(const float *__restrict__ b
 
 hipError_t launch_mdct_forward(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin,
                                uint32_t M, float *coef, hipStream_t s) {
-  if (M == 0) return hipSuccess;
-  const unsigned m_tiles = (M + BM - 1) / BM;
-  hipLaunchKernelGGL(k_mdct_fwd, dim3(m_tiles * 8), dim3(256), 0, s, t, pcm,
-                     static_cast<long long>(frame_begin), M, coef);
-  return hipGetLastError();
+  // Shapes measured with tools/k1_tune.hip (profiles/r01_k1_tune_*.txt).  The f32 VALU needs
+  // >= 4 waves per SIMD to approach its issue rate, so batches that give fewer than ~8
+  // 128x128 tiles per CU use 64x128 tiles with 4x8 outputs per lane (4 workgroups per CU at
+  // BASELINE config 2); larger batches use 128x128 tiles with 8x8 outputs per lane.
+  if (M >= 16384) return k1::launch_sched<128, 128, 16, 3, 0, 8>(t, pcm, frame_begin, M, coef, s);
+  return k1::launch_sched<64, 128, 16, 4, 0, 4>(t, pcm, frame_begin, M, coef, s);
 }
 
 hipError_t launch_quantize(const DeviceTables &t, const float *coef, uint32_t M, uint32_t ch,

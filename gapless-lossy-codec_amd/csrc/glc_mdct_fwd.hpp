@@ -1,0 +1,572 @@
+// glc_mdct_fwd.hpp — K1, the windowed forward MDCT as an exact-order SGEMM on the vector ALU.
+//
+//   C[m][k] = fl( fl( sum_{i ascending} fl( fl(x[m,i]*w[i]) * T[k][i] ) ) * norm )
+//
+// replaces the window loop (src/codec.rs:476-481) and MdctTables::mdct_block (:359-374) of the
+// reference for every frame-channel row m = (frame - frame_begin)*ch + c.  M = rows, N = 1024,
+// K = 2048; the K loop is strictly ascending with ONE accumulator per output, multiply and add
+// are separate instructions (v_pk_mul_f32 / v_pk_add_f32, never an FMA), there is no split-K.
+//
+// The kernel is a template over its tile shape so that tools/k1_tune.hip can time shapes against
+// each other on the GPU; glc_kernels.hip instantiates the one the library ships.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "glc_kernels.h"
+
+namespace glc {
+namespace k1 {
+
+constexpr int kHopI = 1024;
+constexpr int kFrameI = 2048;
+
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+
+// BM x BN output tile per workgroup, BK table rows per LDS stage, TM x TN outputs per lane
+// (TM, TN in {4, 8}: one or two conflict-free ds_read_b128 per operand and i-step),
+// UNROLL i-steps per loop body, MINW = min waves per SIMD for the register allocator.
+template <int BM, int BN, int BK, int TM, int TN, int UNROLL, int MINW>
+struct Cfg {
+  static constexpr int kThreads = (BM / TM) * (BN / TN);
+  static constexpr int kNtx = BN / TN;
+  static constexpr int kNTiles = kHopI / BN;
+  static constexpr int kAPer = BM * BK / kThreads;       // A elements staged per thread
+  static constexpr int kAStride = kThreads / BM;          // i distance between them
+  static constexpr int kBPer = BK * BN / 4 / kThreads;    // B float4 staged per thread
+  static constexpr int kBRowsPer = kThreads / (BN / 4);   // table rows covered per float4 round
+  static_assert(kThreads % BM == 0 && kAPer * kAStride == BK, "A staging shape");
+  static_assert(kThreads % (BN / 4) == 0 && kBPer * kBRowsPer == BK, "B staging shape");
+  static_assert((TM == 4 || TM == 8) && (TN == 4 || TN == 8), "lane tile");
+  static_assert((BK & (BK - 1)) == 0 && BK % UNROLL == 0, "BK");
+};
+
+template <int BM, int BN, int BK, int TM, int TN, int UNROLL, int MINW>
+__global__ __launch_bounds__((BM / TM) * (BN / TN), MINW) void k_mdct_fwd(DeviceTables tb, PcmView pcm,
+                                                                         long long frame_begin,
+                                                                         unsigned M,
+                                                                         float *__restrict__ coef) {
+  using C = Cfg<BM, BN, BK, TM, TN, UNROLL, MINW>;
+  // i-major tiles: As[ii][row], Bs[ii][col]; every ds_read in the inner loop is a b128 whose
+  // 16 lanes of a group cover one contiguous 256-B span (conflict-free).
+  __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+
+  const int tid = threadIdx.x;
+  // blockIdx.x % kNTiles picks the coefficient tile: blocks are dealt round-robin over the 8
+  // XCDs, so each XCD's L2 keeps only 1024/BN/8 panels of T (speed only, never correctness).
+  const int n_tile = blockIdx.x % C::kNTiles;
+  const int m_tile = blockIdx.x / C::kNTiles;
+  const int m0 = m_tile * BM;
+  const int n0 = n_tile * BN;
+  const int tx = tid % C::kNtx, ty = tid / C::kNtx;
+
+  // --- A operand: interleaved PCM read through a buffer descriptor whose hardware range check
+  // supplies the encoder's zero padding (512 leading zeros, tail, shard edges): an element
+  // before the descriptor base wraps to a huge unsigned offset, one past the end is >= the
+  // record count; both load 0.0.  All descriptor inputs are blockIdx/kernarg scalars.
+  const long long ch = pcm.ch;
+  const long long f0 = frame_begin + m0 / pcm.ch;  // first frame of the tile
+  const long long e_first = (f0 * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * ch;
+  long long e_end = static_cast<long long>(pcm.t_count) * ch;  // shard end (elements)
+  const long long n_rel = static_cast<long long>(pcm.n_samples) - static_cast<long long>(pcm.t0) * ch;
+  if (e_end > n_rel) e_end = n_rel;  // stream end
+  const long long e_base = e_first < 0 ? 0 : e_first;
+  long long e_cnt = e_end - e_base;
+  if (e_cnt < 0) e_cnt = 0;
+  if (e_cnt > (1ll << 28)) e_cnt = 1ll << 28;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(pcm.p + e_base), 0, static_cast<int>(e_cnt * 4), 0x00020000);
+
+  // this thread stages ONE row (r = tid % BM) and kAPer of the BK i of a stage
+  const int a_r = tid % BM;
+  const int a_i = tid / BM;
+  const unsigned a_row = m0 + a_r;
+  unsigned a_off = 0x80000000u;  // out-of-range row: every load returns 0
+  if (a_row < M) {
+    const long long f = frame_begin + a_row / pcm.ch;
+    const long long c = a_row % pcm.ch;
+    const long long e_row = (f * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * ch + c;
+    a_off = static_cast<unsigned>((e_row - e_base + a_i * ch) * 4);  // may wrap: that IS the padding
+  }
+  const unsigned a_step = static_cast<unsigned>(C::kAStride * ch * 4);  // bytes between this thread's i's
+  const float *w_ptr = tb.window + a_i;
+  // B operand: float4 (row = idx / (BN/4), col4 = idx % (BN/4)), idx = tid + kThreads j
+  const int b_r = tid / (BN / 4), b_c4 = tid % (BN / 4);
+  const float *b_ptr = tb.cos_t + n0 + static_cast<size_t>(b_r) * kHopI + b_c4 * 4;
+
+  float a_stage[C::kAPer];
+  float4 b_stage[C::kBPer];
+
+  auto load_stage = [&](int i0) {
+    const unsigned off0 = a_off + static_cast<unsigned>(i0) * static_cast<unsigned>(ch * 4);
+#pragma unroll
+    for (int j = 0; j < C::kAPer; ++j) {
+      const float x = __builtin_bit_cast(
+          float, __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, off0 + j * a_step, 0, 0));
+      a_stage[j] = mul_rn(x, w_ptr[i0 + C::kAStride * j]);  // block[i] = slice[i]*window[i], :480
+    }
+#pragma unroll
+    for (int j = 0; j < C::kBPer; ++j)
+      b_stage[j] = *reinterpret_cast<const float4 *>(b_ptr + static_cast<size_t>(i0 + C::kBRowsPer * j) * kHopI);
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < C::kAPer; ++j) As[buf][(a_i + C::kAStride * j) * BM + a_r] = a_stage[j];
+#pragma unroll
+    for (int j = 0; j < C::kBPer; ++j)
+      *reinterpret_cast<float4 *>(&Bs[buf][(b_r + C::kBRowsPer * j) * BN + b_c4 * 4]) = b_stage[j];
+  };
+
+  float acc[TM][TN];
+#pragma unroll
+  for (int r = 0; r < TM; ++r)
+#pragma unroll
+    for (int c = 0; c < TN; ++c) acc[r][c] = 0.0f;  // `let mut s = 0.0f32`, :365
+
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+
+  constexpr int kStages = kFrameI / BK;
+#pragma unroll 1
+  for (int s = 0; s < kStages; ++s) {
+    const int buf = s & 1;
+    // prefetch the next stage into registers (the last iteration re-fetches stage 0 into the
+    // idle buffer: keeps the loop body branch-free)
+    load_stage(((s + 1) & (kStages - 1)) * BK);
+
+    const float *Ab = As[buf] + ty * 4;
+    const float *Bb = Bs[buf] + tx * 4;
+#pragma unroll UNROLL
+    for (int ii = 0; ii < BK; ++ii) {
+      float av[TM], bv[TN];
+      {
+        const float4 v = *reinterpret_cast<const float4 *>(&Ab[ii * BM]);
+        av[0] = v.x; av[1] = v.y; av[2] = v.z; av[3] = v.w;
+      }
+      if constexpr (TM == 8) {
+        const float4 v = *reinterpret_cast<const float4 *>(&Ab[ii * BM + BM / 2]);
+        av[4] = v.x; av[5] = v.y; av[6] = v.z; av[7] = v.w;
+      }
+      {
+        const float4 v = *reinterpret_cast<const float4 *>(&Bb[ii * BN]);
+        bv[0] = v.x; bv[1] = v.y; bv[2] = v.z; bv[3] = v.w;
+      }
+      if constexpr (TN == 8) {
+        const float4 v = *reinterpret_cast<const float4 *>(&Bb[ii * BN + BN / 2]);
+        bv[4] = v.x; bv[5] = v.y; bv[6] = v.z; bv[7] = v.w;
+      }
+#pragma unroll
+      for (int r = 0; r < TM; ++r)
+#pragma unroll
+        for (int c = 0; c < TN; ++c) acc[r][c] = add_rn(acc[r][c], mul_rn(av[r], bv[c]));  // :369
+    }
+
+    store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: out[k] = s * norm, :372
+#pragma unroll
+  for (int r = 0; r < TM; ++r) {
+    const unsigned row = m0 + ((r < 4) ? (ty * 4 + r) : (BM / 2 + ty * 4 + (r - 4)));
+    if (row >= M) continue;
+    float *dst = coef + static_cast<size_t>(row) * kHopI + n0;
+    float4 o;
+    o.x = mul_rn(acc[r][0], tb.norm); o.y = mul_rn(acc[r][1], tb.norm);
+    o.z = mul_rn(acc[r][2], tb.norm); o.w = mul_rn(acc[r][3], tb.norm);
+    *reinterpret_cast<float4 *>(dst + tx * 4) = o;
+    if constexpr (TN == 8) {
+      o.x = mul_rn(acc[r][4], tb.norm); o.y = mul_rn(acc[r][5], tb.norm);
+      o.z = mul_rn(acc[r][6], tb.norm); o.w = mul_rn(acc[r][7], tb.norm);
+      *reinterpret_cast<float4 *>(dst + BN / 2 + tx * 4) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Hand-scheduled variant (8x8 outputs per lane).  Same arithmetic, but the instruction order
+// is pinned with inline asm because hipcc (ROCm 7.2) (a) places every v_pk_add directly behind
+// the v_pk_mul it depends on and (b) sinks the LDS reads of the next i-step below the current
+// step's math, so a wave stalls on both.  Here each i-step issues its 8 ds_read_b64 for the NEXT
+// step first, then 4 groups of {8 v_pk_mul, 8 v_pk_add} (dependent instructions 8 apart), then
+// one s_waitcnt: register set X feeds even steps, set Y odd steps (ping-pong, no copies).
+// ------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Operands {  // one i-step's A (8 rows) and B (8 columns) values of this lane
+  f32x2 a0, a1, a2, a3, b0, b1, b2, b3;
+};
+
+template <int BM, int BN>
+__device__ __forceinline__ void lds_fetch4(Operands &o, unsigned a_addr, unsigned b_addr, int ii) {
+  // 4-row lane tile: rows ty*4 .. ty*4+3 only (a2/a3 unused)
+  asm volatile(
+      "ds_read_b64 %0, %6 offset:%c8\n\t"
+      "ds_read_b64 %1, %6 offset:%c9\n\t"
+      "ds_read_b64 %2, %7 offset:%c10\n\t"
+      "ds_read_b64 %3, %7 offset:%c11\n\t"
+      "ds_read_b64 %4, %7 offset:%c12\n\t"
+      "ds_read_b64 %5, %7 offset:%c13"
+      : "=&v"(o.a0), "=&v"(o.a1), "=&v"(o.b0), "=&v"(o.b1), "=&v"(o.b2), "=&v"(o.b3)
+      : "v"(a_addr), "v"(b_addr), "i"(ii * BM * 4), "i"(ii * BM * 4 + 8), "i"(ii * BN * 4), "i"(ii * BN * 4 + 8),
+        "i"(ii * BN * 4 + BN * 2), "i"(ii * BN * 4 + BN * 2 + 8)
+      : "memory");
+}
+
+__device__ __forceinline__ void lds_wait4(Operands &o) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(o.a0), "+v"(o.a1), "+v"(o.b0), "+v"(o.b1), "+v"(o.b2), "+v"(o.b3)
+               :
+               : "memory");
+}
+
+template <int BM, int BN>
+__device__ __forceinline__ void lds_fetch(Operands &o, unsigned a_addr, unsigned b_addr, int ii) {
+  // asm loads: hipcc does not count them; every use is behind lds_wait() (cdna guide §5.7 iii).
+  // Outputs are early-clobber: the first ds_read must not land on the address registers the
+  // later ones still need.
+  asm volatile(
+      "ds_read_b64 %0, %8 offset:%c10\n\t"
+      "ds_read_b64 %1, %8 offset:%c11\n\t"
+      "ds_read_b64 %2, %8 offset:%c12\n\t"
+      "ds_read_b64 %3, %8 offset:%c13\n\t"
+      "ds_read_b64 %4, %9 offset:%c14\n\t"
+      "ds_read_b64 %5, %9 offset:%c15\n\t"
+      "ds_read_b64 %6, %9 offset:%c16\n\t"
+      "ds_read_b64 %7, %9 offset:%c17"
+      : "=&v"(o.a0), "=&v"(o.a1), "=&v"(o.a2), "=&v"(o.a3), "=&v"(o.b0), "=&v"(o.b1), "=&v"(o.b2), "=&v"(o.b3)
+      : "v"(a_addr), "v"(b_addr), "i"(ii * BM * 4), "i"(ii * BM * 4 + 8), "i"(ii * BM * 4 + BM * 2),
+        "i"(ii * BM * 4 + BM * 2 + 8), "i"(ii * BN * 4), "i"(ii * BN * 4 + 8), "i"(ii * BN * 4 + BN * 2),
+        "i"(ii * BN * 4 + BN * 2 + 8)
+      : "memory");
+}
+
+__device__ __forceinline__ void lds_wait(Operands &o) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(o.a0), "+v"(o.a1), "+v"(o.a2), "+v"(o.a3), "+v"(o.b0), "+v"(o.b1), "+v"(o.b2), "+v"(o.b3)
+               :
+               : "memory");
+}
+
+// rows (r, r+1) x 8 columns: c[r][j] += a.lo * b_j ; c[r+1][j] += a.hi * b_j   (j = column pair)
+__device__ __forceinline__ void mac2rows(f32x2 (&c0)[4], f32x2 (&c1)[4], f32x2 a, f32x2 b0, f32x2 b1,
+                                         f32x2 b2, f32x2 b3) {
+  f32x2 t0, t1, t2, t3, t4, t5, t6, t7;
+  asm volatile(
+      "v_pk_mul_f32 %8, %16, %17 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %9, %16, %18 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %10, %16, %19 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %11, %16, %20 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %12, %16, %17 op_sel:[1,0]\n\t"
+      "v_pk_mul_f32 %13, %16, %18 op_sel:[1,0]\n\t"
+      "v_pk_mul_f32 %14, %16, %19 op_sel:[1,0]\n\t"
+      "v_pk_mul_f32 %15, %16, %20 op_sel:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, %8\n\t"
+      "v_pk_add_f32 %1, %1, %9\n\t"
+      "v_pk_add_f32 %2, %2, %10\n\t"
+      "v_pk_add_f32 %3, %3, %11\n\t"
+      "v_pk_add_f32 %4, %4, %12\n\t"
+      "v_pk_add_f32 %5, %5, %13\n\t"
+      "v_pk_add_f32 %6, %6, %14\n\t"
+      "v_pk_add_f32 %7, %7, %15"
+      : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3]),
+        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+      : "v"(a), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+}
+
+// One whole i-step of a 4x8 lane tile as ONE asm statement (no compiler pads between groups):
+// issue the next step's six ds_read_b64 (into n), do this step's 32 multiplies and 32 adds from
+// c (dependent instructions 8 apart), then wait for the reads.  r<row><colpair> = accumulators.
+template <int BM, int BN, bool FETCH>
+__device__ __forceinline__ void step4(f32x2 (&acc)[4][4], const Operands &c, Operands &n, unsigned a_addr,
+                                      unsigned b_addr, int ii_next) {
+  f32x2 t0, t1, t2, t3, t4, t5, t6, t7;
+  // named operands keep the string readable: [r<row><colpair>]
+  if constexpr (FETCH) {
+    asm volatile(
+        "ds_read_b64 %[na0], %[aa] offset:%c[oa0]\n\t"
+        "ds_read_b64 %[na1], %[aa] offset:%c[oa1]\n\t"
+        "ds_read_b64 %[nb0], %[ba] offset:%c[ob0]\n\t"
+        "ds_read_b64 %[nb1], %[ba] offset:%c[ob1]\n\t"
+        "ds_read_b64 %[nb2], %[ba] offset:%c[ob2]\n\t"
+        "ds_read_b64 %[nb3], %[ba] offset:%c[ob3]\n\t"
+        "v_pk_mul_f32 %[t0], %[ca0], %[cb0] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[t1], %[ca0], %[cb1] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[t2], %[ca0], %[cb2] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[t3], %[ca0], %[cb3] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[t4], %[ca0], %[cb0] op_sel:[1,0]\n\t"
+        "v_pk_mul_f32 %[t5], %[ca0], %[cb1] op_sel:[1,0]\n\t"
+        "v_pk_mul_f32 %[t6], %[ca0], %[cb2] op_sel:[1,0]\n\t"
+        "v_pk_mul_f32 %[t7], %[ca0], %[cb3] op_sel:[1,0]\n\t"
+        "v_pk_add_f32 %[r00], %[r00], %[t0]\n\t"
+        "v_pk_add_f32 %[r01], %[r01], %[t1]\n\t"
+        "v_pk_add_f32 %[r02], %[r02], %[t2]\n\t"
+        "v_pk_add_f32 %[r03], %[r03], %[t3]\n\t"
+        "v_pk_add_f32 %[r10], %[r10], %[t4]\n\t"
+        "v_pk_add_f32 %[r11], %[r11], %[t5]\n\t"
+        "v_pk_add_f32 %[r12], %[r12], %[t6]\n\t"
+        "v_pk_add_f32 %[r13], %[r13], %[t7]\n\t"
+        "v_pk_mul_f32 %[t0], %[ca1], %[cb0] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[t1], %[ca1], %[cb1] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[t2], %[ca1], %[cb2] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[t3], %[ca1], %[cb3] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[t4], %[ca1], %[cb0] op_sel:[1,0]\n\t"
+        "v_pk_mul_f32 %[t5], %[ca1], %[cb1] op_sel:[1,0]\n\t"
+        "v_pk_mul_f32 %[t6], %[ca1], %[cb2] op_sel:[1,0]\n\t"
+        "v_pk_mul_f32 %[t7], %[ca1], %[cb3] op_sel:[1,0]\n\t"
+        "v_pk_add_f32 %[r20], %[r20], %[t0]\n\t"
+        "v_pk_add_f32 %[r21], %[r21], %[t1]\n\t"
+        "v_pk_add_f32 %[r22], %[r22], %[t2]\n\t"
+        "v_pk_add_f32 %[r23], %[r23], %[t3]\n\t"
+        "v_pk_add_f32 %[r30], %[r30], %[t4]\n\t"
+        "v_pk_add_f32 %[r31], %[r31], %[t5]\n\t"
+        "v_pk_add_f32 %[r32], %[r32], %[t6]\n\t"
+        "v_pk_add_f32 %[r33], %[r33], %[t7]\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : [r00] "+v"(acc[0][0]), [r01] "+v"(acc[0][1]), [r02] "+v"(acc[0][2]), [r03] "+v"(acc[0][3]),
+          [r10] "+v"(acc[1][0]), [r11] "+v"(acc[1][1]), [r12] "+v"(acc[1][2]), [r13] "+v"(acc[1][3]),
+          [r20] "+v"(acc[2][0]), [r21] "+v"(acc[2][1]), [r22] "+v"(acc[2][2]), [r23] "+v"(acc[2][3]),
+          [r30] "+v"(acc[3][0]), [r31] "+v"(acc[3][1]), [r32] "+v"(acc[3][2]), [r33] "+v"(acc[3][3]),
+          [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5),
+          [t6] "=&v"(t6), [t7] "=&v"(t7), [na0] "=&v"(n.a0), [na1] "=&v"(n.a1), [nb0] "=&v"(n.b0),
+          [nb1] "=&v"(n.b1), [nb2] "=&v"(n.b2), [nb3] "=&v"(n.b3)
+        : [ca0] "v"(c.a0), [ca1] "v"(c.a1), [cb0] "v"(c.b0), [cb1] "v"(c.b1), [cb2] "v"(c.b2), [cb3] "v"(c.b3),
+          [aa] "v"(a_addr), [ba] "v"(b_addr), [oa0] "i"(ii_next * BM * 4), [oa1] "i"(ii_next * BM * 4 + 8),
+          [ob0] "i"(ii_next * BN * 4), [ob1] "i"(ii_next * BN * 4 + 8), [ob2] "i"(ii_next * BN * 4 + BN * 2),
+          [ob3] "i"(ii_next * BN * 4 + BN * 2 + 8)
+        : "memory");
+  } else {
+    asm volatile(
+        "v_pk_mul_f32 %[t0], %[ca0], %[cb0] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[t1], %[ca0], %[cb1] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[t2], %[ca0], %[cb2] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[t3], %[ca0], %[cb3] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[t4], %[ca0], %[cb0] op_sel:[1,0]\n\t"
+        "v_pk_mul_f32 %[t5], %[ca0], %[cb1] op_sel:[1,0]\n\t"
+        "v_pk_mul_f32 %[t6], %[ca0], %[cb2] op_sel:[1,0]\n\t"
+        "v_pk_mul_f32 %[t7], %[ca0], %[cb3] op_sel:[1,0]\n\t"
+        "v_pk_add_f32 %[r00], %[r00], %[t0]\n\t"
+        "v_pk_add_f32 %[r01], %[r01], %[t1]\n\t"
+        "v_pk_add_f32 %[r02], %[r02], %[t2]\n\t"
+        "v_pk_add_f32 %[r03], %[r03], %[t3]\n\t"
+        "v_pk_add_f32 %[r10], %[r10], %[t4]\n\t"
+        "v_pk_add_f32 %[r11], %[r11], %[t5]\n\t"
+        "v_pk_add_f32 %[r12], %[r12], %[t6]\n\t"
+        "v_pk_add_f32 %[r13], %[r13], %[t7]\n\t"
+        "v_pk_mul_f32 %[t0], %[ca1], %[cb0] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[t1], %[ca1], %[cb1] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[t2], %[ca1], %[cb2] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[t3], %[ca1], %[cb3] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[t4], %[ca1], %[cb0] op_sel:[1,0]\n\t"
+        "v_pk_mul_f32 %[t5], %[ca1], %[cb1] op_sel:[1,0]\n\t"
+        "v_pk_mul_f32 %[t6], %[ca1], %[cb2] op_sel:[1,0]\n\t"
+        "v_pk_mul_f32 %[t7], %[ca1], %[cb3] op_sel:[1,0]\n\t"
+        "v_pk_add_f32 %[r20], %[r20], %[t0]\n\t"
+        "v_pk_add_f32 %[r21], %[r21], %[t1]\n\t"
+        "v_pk_add_f32 %[r22], %[r22], %[t2]\n\t"
+        "v_pk_add_f32 %[r23], %[r23], %[t3]\n\t"
+        "v_pk_add_f32 %[r30], %[r30], %[t4]\n\t"
+        "v_pk_add_f32 %[r31], %[r31], %[t5]\n\t"
+        "v_pk_add_f32 %[r32], %[r32], %[t6]\n\t"
+        "v_pk_add_f32 %[r33], %[r33], %[t7]"
+        : [r00] "+v"(acc[0][0]), [r01] "+v"(acc[0][1]), [r02] "+v"(acc[0][2]), [r03] "+v"(acc[0][3]),
+          [r10] "+v"(acc[1][0]), [r11] "+v"(acc[1][1]), [r12] "+v"(acc[1][2]), [r13] "+v"(acc[1][3]),
+          [r20] "+v"(acc[2][0]), [r21] "+v"(acc[2][1]), [r22] "+v"(acc[2][2]), [r23] "+v"(acc[2][3]),
+          [r30] "+v"(acc[3][0]), [r31] "+v"(acc[3][1]), [r32] "+v"(acc[3][2]), [r33] "+v"(acc[3][3]),
+          [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5),
+          [t6] "=&v"(t6), [t7] "=&v"(t7)
+        : [ca0] "v"(c.a0), [ca1] "v"(c.a1), [cb0] "v"(c.b0), [cb1] "v"(c.b1), [cb2] "v"(c.b2), [cb3] "v"(c.b3));
+  }
+}
+
+template <int TM>
+__device__ __forceinline__ void mac_step(f32x2 (&acc)[TM][4], const Operands &o) {
+  mac2rows(acc[0], acc[1], o.a0, o.b0, o.b1, o.b2, o.b3);
+  mac2rows(acc[2], acc[3], o.a1, o.b0, o.b1, o.b2, o.b3);
+  if constexpr (TM == 8) {
+    mac2rows(acc[4], acc[5], o.a2, o.b0, o.b1, o.b2, o.b3);
+    mac2rows(acc[6], acc[7], o.a3, o.b0, o.b1, o.b2, o.b3);
+  }
+}
+
+// ABL (tuning only, results are wrong when != 0): 1 = no staging/barrier inside the stage loop,
+// 2 = additionally no LDS operand reads inside the loop (pure VALU stream).
+template <int BM, int BN, int BK, int MINW, int ABL = 0, int TM = 8>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MINW, MINW))) void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm,
+                                                               long long frame_begin, unsigned M,
+                                                               float *__restrict__ coef) {
+  using C = Cfg<BM, BN, BK, TM, 8, 2, MINW>;
+  static_assert(C::kThreads == 256, "TMx8 lane tile, 256 threads");
+  __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+
+  const int tid = threadIdx.x;
+  const int n_tile = blockIdx.x % C::kNTiles;
+  const int m_tile = blockIdx.x / C::kNTiles;
+  const int m0 = m_tile * BM;
+  const int n0 = n_tile * BN;
+  const int tx = tid % C::kNtx, ty = tid / C::kNtx;
+
+  const long long ch = pcm.ch;
+  const long long f0 = frame_begin + m0 / pcm.ch;
+  const long long e_first = (f0 * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * ch;
+  long long e_end = static_cast<long long>(pcm.t_count) * ch;
+  const long long n_rel = static_cast<long long>(pcm.n_samples) - static_cast<long long>(pcm.t0) * ch;
+  if (e_end > n_rel) e_end = n_rel;
+  const long long e_base = e_first < 0 ? 0 : e_first;
+  long long e_cnt = e_end - e_base;
+  if (e_cnt < 0) e_cnt = 0;
+  if (e_cnt > (1ll << 28)) e_cnt = 1ll << 28;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(pcm.p + e_base), 0, static_cast<int>(e_cnt * 4), 0x00020000);
+
+  const int a_r = tid % BM;
+  const int a_i = tid / BM;
+  const unsigned a_row = m0 + a_r;
+  unsigned a_off = 0x80000000u;
+  if (a_row < M) {
+    const long long f = frame_begin + a_row / pcm.ch;
+    const long long c = a_row % pcm.ch;
+    const long long e_row = (f * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * ch + c;
+    a_off = static_cast<unsigned>((e_row - e_base + a_i * ch) * 4);
+  }
+  const unsigned a_step = static_cast<unsigned>(C::kAStride * ch * 4);
+  const float *w_ptr = tb.window + a_i;
+  const int b_r = tid / (BN / 4), b_c4 = tid % (BN / 4);
+  const float *b_ptr = tb.cos_t + n0 + static_cast<size_t>(b_r) * kHopI + b_c4 * 4;
+
+  // staging registers: raw sample and window value are multiplied only when the stage is
+  // written to LDS, so the wave waits for its global loads at the END of the stage
+  float a_raw[C::kAPer], a_win[C::kAPer];
+  f32x4 b_stage[C::kBPer];
+  auto load_stage = [&](int i0) {
+    const unsigned off0 = a_off + static_cast<unsigned>(i0) * static_cast<unsigned>(ch * 4);
+#pragma unroll
+    for (int j = 0; j < C::kAPer; ++j) {
+      a_raw[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, off0 + j * a_step, 0, 0));
+      a_win[j] = w_ptr[i0 + C::kAStride * j];
+    }
+#pragma unroll
+    for (int j = 0; j < C::kBPer; ++j)
+      b_stage[j] = *reinterpret_cast<const f32x4 *>(b_ptr + static_cast<size_t>(i0 + C::kBRowsPer * j) * kHopI);
+  };
+  auto store_stage = [&](int buf) {
+    // pin the first use of the staged registers behind the stage's math (volatile asm
+    // statements keep their order): hipcc otherwise hoists the multiply, and with it the
+    // vmcnt wait, into the middle of the stage
+#pragma unroll
+    for (int j = 0; j < C::kAPer; ++j) {
+      float r = a_raw[j], w = a_win[j];
+      asm volatile("" : "+v"(r), "+v"(w));
+      As[buf][(a_i + C::kAStride * j) * BM + a_r] = mul_rn(r, w);  // block[i] = slice[i]*window[i], :480
+    }
+#pragma unroll
+    for (int j = 0; j < C::kBPer; ++j) {
+      f32x4 b = b_stage[j];
+      asm volatile("" : "+v"(b));
+      *reinterpret_cast<f32x4 *>(&Bs[buf][(b_r + C::kBRowsPer * j) * BN + b_c4 * 4]) = b;
+    }
+  };
+
+  f32x2 acc[TM][4];
+#pragma unroll
+  for (int r = 0; r < TM; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = f32x2{0.0f, 0.0f};
+  auto fetch = [&](Operands &o, unsigned a_addr, unsigned b_addr, int ii) {
+    if constexpr (TM == 8) lds_fetch<BM, BN>(o, a_addr, b_addr, ii);
+    else lds_fetch4<BM, BN>(o, a_addr, b_addr, ii);
+  };
+  auto wait = [&](Operands &o) {
+    if constexpr (TM == 8) lds_wait(o);
+    else lds_wait4(o);
+  };
+
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+
+  // LDS byte addresses of this lane's operand columns (low 32 bits of a generic LDS pointer)
+  const unsigned a_lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(&As[0][ty * 4]));
+  const unsigned b_lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(&Bs[0][tx * 4]));
+
+  constexpr int kStages = kFrameI / BK;
+#pragma unroll 1
+  for (int s = 0; s < kStages; ++s) {
+    const int buf = s & 1;
+    if (ABL == 0) load_stage(((s + 1) & (kStages - 1)) * BK);
+    const unsigned a_addr = a_lds0 + buf * (BK * BM * 4);
+    const unsigned b_addr = b_lds0 + buf * (BK * BN * 4);
+    Operands X, Y;
+    fetch(X, a_addr, b_addr, 0);
+    wait(X);
+    if (ABL == 2) {
+      fetch(Y, a_addr, b_addr, 1);
+      wait(Y);
+    }
+    if constexpr (TM == 4 && ABL != 2) {
+#pragma unroll
+      for (int ii = 0; ii < BK; ii += 2) {
+        step4<BM, BN, true>(acc, X, Y, a_addr, b_addr, ii + 1);
+        if (ii + 2 < BK) step4<BM, BN, true>(acc, Y, X, a_addr, b_addr, ii + 2);
+        else step4<BM, BN, false>(acc, Y, X, a_addr, b_addr, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ii = 0; ii < BK; ii += 2) {
+        if (ABL != 2) fetch(Y, a_addr, b_addr, ii + 1);
+        mac_step<TM>(acc, X);
+        if (ABL != 2) wait(Y);
+        if (ABL != 2 && ii + 2 < BK) fetch(X, a_addr, b_addr, ii + 2);
+        mac_step<TM>(acc, Y);
+        if (ABL != 2 && ii + 2 < BK) wait(X);
+      }
+    }
+    if (ABL == 0) {
+      store_stage(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int r = 0; r < TM; ++r) {
+    const unsigned row = m0 + ((r < 4) ? (ty * 4 + r) : (BM / 2 + ty * 4 + (r - 4)));
+    if (row >= M) continue;
+    float *dst = coef + static_cast<size_t>(row) * kHopI + n0;
+    float4 o;
+    o.x = mul_rn(acc[r][0].x, tb.norm); o.y = mul_rn(acc[r][0].y, tb.norm);
+    o.z = mul_rn(acc[r][1].x, tb.norm); o.w = mul_rn(acc[r][1].y, tb.norm);
+    *reinterpret_cast<float4 *>(dst + tx * 4) = o;
+    o.x = mul_rn(acc[r][2].x, tb.norm); o.y = mul_rn(acc[r][2].y, tb.norm);
+    o.z = mul_rn(acc[r][3].x, tb.norm); o.w = mul_rn(acc[r][3].y, tb.norm);
+    *reinterpret_cast<float4 *>(dst + BN / 2 + tx * 4) = o;
+  }
+}
+
+template <int BM, int BN, int BK, int MINW, int ABL = 0, int TM = 8>
+inline hipError_t launch_sched(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M,
+                               float *coef, hipStream_t s) {
+  using C = Cfg<BM, BN, BK, TM, 8, 2, MINW>;
+  if (M == 0) return hipSuccess;
+  const unsigned m_tiles = (M + BM - 1) / BM;
+  hipLaunchKernelGGL((k_mdct_fwd_sched<BM, BN, BK, MINW, ABL, TM>), dim3(m_tiles * C::kNTiles), dim3(256), 0, s, t, pcm,
+                     static_cast<long long>(frame_begin), M, coef);
+  return hipGetLastError();
+}
+
+template <int BM, int BN, int BK, int TM, int TN, int UNROLL, int MINW>
+inline hipError_t launch(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M,
+                         float *coef, hipStream_t s) {
+  using C = Cfg<BM, BN, BK, TM, TN, UNROLL, MINW>;
+  if (M == 0) return hipSuccess;
+  const unsigned m_tiles = (M + BM - 1) / BM;
+  hipLaunchKernelGGL((k_mdct_fwd<BM, BN, BK, TM, TN, UNROLL, MINW>), dim3(m_tiles * C::kNTiles),
+                     dim3(C::kThreads), 0, s, t, pcm, static_cast<long long>(frame_begin), M, coef);
+  return hipGetLastError();
+}
+
+}  // namespace k1
+}  // namespace glc

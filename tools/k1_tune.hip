@@ -1,0 +1,131 @@
+// k1_tune.hip — times tile-shape variants of the forward-MDCT kernel (glc_mdct_fwd.hpp) against
+// each other on the GPU and checks every variant bit-for-bit against a naive one-output-per-lane
+// kernel that accumulates in the reference's order.  Development tool, not part of the library.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I gapless-lossy-codec_amd/csrc \
+//        tools/k1_tune.hip -o build/k1_tune
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "glc_mdct_fwd.hpp"
+
+#pragma clang fp contract(off)
+
+#define CHECK(x)                                                                   \
+  do {                                                                             \
+    hipError_t e = (x);                                                            \
+    if (e != hipSuccess) {                                                         \
+      printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); \
+      exit(1);                                                                     \
+    }                                                                              \
+  } while (0)
+
+using namespace glc;
+
+// naive reference: one (row, k) per thread, i ascending, separate mul and add
+__global__ void k_naive(DeviceTables tb, PcmView pcm, long long frame_begin, unsigned M, float *coef) {
+  const unsigned k = blockIdx.x * 256 + threadIdx.x;
+  const unsigned m = blockIdx.y;
+  if (m >= M || k >= 1024) return;
+  const long long f = frame_begin + m / pcm.ch;
+  const unsigned c = m % pcm.ch;
+  float s = 0.f;
+  for (int i = 0; i < 2048; ++i) {
+    const long long t = f * 1024 + i - 512;
+    float x = 0.f;
+    if (t >= 0) {
+      const unsigned long long idx = (unsigned long long)t * pcm.ch + c;
+      if (idx < pcm.n_samples && (unsigned long long)t >= pcm.t0 && (unsigned long long)t - pcm.t0 < pcm.t_count)
+        x = pcm.p[((unsigned long long)t - pcm.t0) * pcm.ch + c];
+    }
+    const float b = __fmul_rn(x, tb.window[i]);
+    s = __fadd_rn(s, __fmul_rn(b, tb.cos_t[(size_t)i * 1024 + k]));
+  }
+  coef[(size_t)m * 1024 + k] = __fmul_rn(s, tb.norm);
+}
+
+struct Variant {
+  std::string name;
+  std::function<hipError_t(const DeviceTables &, const PcmView &, uint64_t, uint32_t, float *, hipStream_t)> fn;
+};
+
+#define V(BM, BN, BK, TM, TN, UN, MW) \
+  Variant { #BM "x" #BN " bk" #BK " t" #TM "x" #TN " u" #UN " w" #MW, k1::launch<BM, BN, BK, TM, TN, UN, MW> }
+
+int main(int argc, char **argv) {
+  const int frames = argc > 1 ? atoi(argv[1]) : 4096;
+  const unsigned ch = argc > 2 ? atoi(argv[2]) : 2;
+  const int reps = argc > 3 ? atoi(argv[3]) : 10;
+  const uint64_t L = (uint64_t)frames * 1024;
+  const uint64_t n_samples = L * ch;
+  const uint32_t M = frames * ch;
+
+  std::vector<float> h_cos_t((size_t)2048 * 1024), h_win(2048), h_pcm(n_samples);
+  srand(1);
+  for (auto &v : h_cos_t) v = cosf((float)(rand() % 100000) * 0.001f);
+  for (int i = 0; i < 2048; ++i) h_win[i] = sinf(3.14159265f * (i + 0.5f) / 2048.f);
+  for (auto &v : h_pcm) v = ((rand() % 20001) - 10000) * 1e-4f * 0.3f;
+
+  float *d_cos_t, *d_win, *d_pcm, *d_ref, *d_out;
+  CHECK(hipMalloc(&d_cos_t, h_cos_t.size() * 4));
+  CHECK(hipMalloc(&d_win, 2048 * 4));
+  CHECK(hipMalloc(&d_pcm, n_samples * 4));
+  CHECK(hipMalloc(&d_ref, (size_t)M * 1024 * 4));
+  CHECK(hipMalloc(&d_out, (size_t)M * 1024 * 4));
+  CHECK(hipMemcpy(d_cos_t, h_cos_t.data(), h_cos_t.size() * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_win, h_win.data(), 2048 * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_pcm, h_pcm.data(), n_samples * 4, hipMemcpyHostToDevice));
+
+  DeviceTables tb{};
+  tb.cos_t = d_cos_t;
+  tb.window = d_win;
+  tb.norm = 0.044194173f;
+  PcmView pcm{d_pcm, 0, L, n_samples, ch};
+
+  hipLaunchKernelGGL(k_naive, dim3(4, M), dim3(256), 0, 0, tb, pcm, 0ll, M, d_ref);
+  CHECK(hipDeviceSynchronize());
+  std::vector<uint32_t> ref((size_t)M * 1024), out((size_t)M * 1024);
+  CHECK(hipMemcpy(ref.data(), d_ref, ref.size() * 4, hipMemcpyDeviceToHost));
+
+  std::vector<Variant> vs = {
+      Variant{"sched 128x128 bk16 t8 w3", k1::launch_sched<128, 128, 16, 3>},
+      Variant{"sched 128x128 bk16 t8 w3 ABL1", k1::launch_sched<128, 128, 16, 3, 1>},
+      Variant{"sched 128x128 bk16 t8 w3 ABL2", k1::launch_sched<128, 128, 16, 3, 2>},
+      Variant{"sched 64x128 bk16 t4 w4", k1::launch_sched<64, 128, 16, 4, 0, 4>},
+      Variant{"sched 64x128 bk16 t4 w4 ABL1", k1::launch_sched<64, 128, 16, 4, 1, 4>},
+      Variant{"sched 64x128 bk16 t4 w4 ABL2", k1::launch_sched<64, 128, 16, 4, 2, 4>},
+  };
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  const double macs = (double)M * 1024.0 * 2048.0;
+  for (auto &v : vs) {
+    CHECK(hipMemset(d_out, 0xFF, (size_t)M * 1024 * 4));
+    CHECK(v.fn(tb, pcm, 0, M, d_out, 0));
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0;
+    for (size_t i = 0; i < ref.size(); ++i) bad += ref[i] != out[i];
+    float best = 1e30f, sum = 0;
+    for (int r = 0; r < reps; ++r) {
+      CHECK(hipEventRecord(e0));
+      CHECK(v.fn(tb, pcm, 0, M, d_out, 0));
+      CHECK(hipEventRecord(e1));
+      CHECK(hipEventSynchronize(e1));
+      float ms;
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      best = ms < best ? ms : best;
+      sum += ms;
+    }
+    printf("%-28s  best %7.3f ms  avg %7.3f ms  %6.2f T unfused-MAC/s  mismatches %zu\n", v.name.c_str(), best,
+           sum / reps, macs / (best * 1e-3) * 1e-12, bad);
+    fflush(stdout);
+  }
+  return 0;
+}

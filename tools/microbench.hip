@@ -83,6 +83,36 @@ __global__ __launch_bounds__(256) void k_packed(float *out, const float *in, int
   out[blockIdx.x * 256 + threadIdx.x] = s.x + s.y;
 }
 
+// B2: as B but with the lane-broadcast op_sel forms the MDCT kernel uses
+__global__ __launch_bounds__(256) void k_packed_bcast(float *out, const float *in, int iters) {
+  f32x2 acc[32];
+  f32x2 a = {in[threadIdx.x & 63], in[(threadIdx.x + 1) & 63]};
+  f32x2 b[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b[j] = f32x2{in[64 + j], in[72 + j]};
+#pragma unroll
+  for (int j = 0; j < 32; ++j) acc[j] = f32x2{0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x2 t[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t[j]) : "v"(a), "v"(b[j]));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(t[4 + j]) : "v"(a), "v"(b[j]));
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(acc[g * 8 + j]) : "v"(t[j]));
+    }
+  }
+  f32x2 s = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 32; ++j) s += acc[j];
+  out[blockIdx.x * 256 + threadIdx.x] = s.x + s.y;
+}
+
 // C: products on the matrix pipe (32x32x1, 2 blocks, C = 0), adds on the VALU
 template <int PK>
 __global__ __launch_bounds__(256) void k_mfma_add(float *out, const float *in, int iters) {
@@ -147,7 +177,7 @@ static int run(const char *name, F launch, double macs_per_thread_iter, int iter
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  for (int wg_per_cu = 1; wg_per_cu <= 4; wg_per_cu *= 2) {
+  for (int wg_per_cu = 1; wg_per_cu <= 8; wg_per_cu *= 2) {
     const int grid = 256 * wg_per_cu;
     launch(grid, iters / 8);  // warm-up
     CHECK(hipDeviceSynchronize());
@@ -172,13 +202,14 @@ static int run(const char *name, F launch, double macs_per_thread_iter, int iter
 int main() {
   float *in, *out;
   CHECK(hipMalloc(&in, 4096));
-  CHECK(hipMalloc(&out, 256 * 4 * 256 * sizeof(float)));
+  CHECK(hipMalloc(&out, (size_t)256 * 8 * 256 * sizeof(float)));  // largest grid: 256 CUs x 8 WGs
   std::vector<float> h(1024);
   for (int i = 0; i < 1024; ++i) h[i] = 0.5f + 0.001f * (i % 97);
   CHECK(hipMemcpy(in, h.data(), 4096, hipMemcpyHostToDevice));
   const int iters = 20000;
   run("A v_mul+v_add", [&](int g, int it) { hipLaunchKernelGGL(k_scalar, dim3(g), dim3(256), 0, 0, out, in, it); }, 32.0, iters);
   run("B v_pk_mul+v_pk_add", [&](int g, int it) { hipLaunchKernelGGL(k_packed, dim3(g), dim3(256), 0, 0, out, in, it); }, 64.0, iters);
+  run("B2 pk with op_sel broadcast", [&](int g, int it) { hipLaunchKernelGGL(k_packed_bcast, dim3(g), dim3(256), 0, 0, out, in, it); }, 64.0, iters);
   run("C mfma32x32x1_2b + v_add", [&](int g, int it) { hipLaunchKernelGGL(k_mfma_add<0>, dim3(g), dim3(256), 0, 0, out, in, it); }, 32.0, iters);
   run("C' mfma32x32x1_2b + pk_add", [&](int g, int it) { hipLaunchKernelGGL(k_mfma_add<1>, dim3(g), dim3(256), 0, 0, out, in, it); }, 32.0, iters);
   run("D mfma32x32x1_2b only", [&](int g, int it) { hipLaunchKernelGGL(k_mfma_only, dim3(g), dim3(256), 0, 0, out, in, it); }, 32.0, iters);
