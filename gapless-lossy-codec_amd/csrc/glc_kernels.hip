@@ -71,7 +71,12 @@ __global__ __launch_bounds__(256) void k_quantize(DeviceTables tb, const float *
     for (int j = 0; j < 4; ++j) {
       c4[j] = src[lane + 64 * j];
       amax = fmaxf(amax, fmaxf(fmaxf(fabsf(c4[j].x), fabsf(c4[j].y)), fmaxf(fabsf(c4[j].z), fabsf(c4[j].w))));
-      *reinterpret_cast<float4 *>(&srow[w][(lane + 64 * j) * 4]) = c4[j];
+      // squares are formed in parallel (each is one rounding, order-free); only the SUM below
+      // has to follow the reference's ascending order (src/codec.rs:212-214)
+      float4 sq;
+      sq.x = mul_rn(c4[j].x, c4[j].x); sq.y = mul_rn(c4[j].y, c4[j].y);
+      sq.z = mul_rn(c4[j].z, c4[j].z); sq.w = mul_rn(c4[j].w, c4[j].w);
+      *reinterpret_cast<float4 *>(&srow[w][(lane + 64 * j) * 4]) = sq;
     }
   }
 #pragma unroll
@@ -81,11 +86,17 @@ __global__ __launch_bounds__(256) void k_quantize(DeviceTables tb, const float *
 
   if (live && lane < static_cast<int>(tb.n_bands)) {
     const unsigned lo = tb.edges[lane], hi = tb.edges[lane + 1];
+    const float *sq = srow[w];
     float ss = 0.0f;
-    for (unsigned i = lo; i < hi; ++i) {
-      const float v = srow[w][i];
-      ss = add_rn(ss, mul_rn(v, v));  // :212-214, ascending i
+    unsigned i = lo;
+    for (; i + 8 <= hi; i += 8) {  // 8 LDS reads in flight, then the 8 dependent adds
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = sq[i + j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss = add_rn(ss, v[j]);
     }
+    for (; i < hi; ++i) ss = add_rn(ss, sq[i]);
     const float energy = sqrtf(ss / tb.band_len[lane]);                       // :214-215
     const float base = mul_rn(mul_rn(mul_rn(energy, 0.01f), tb.cf), tb.band_pf[lane]);  // :223
     sbase[w][lane] = base;
