@@ -74,11 +74,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU fallback)"
+    # GLC_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks
+    # then share devices and the gather goes through host memory); the real run uses nccl = RCCL.
+    backend = os.environ.get("GLC_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- inputs resident in HBM before the timed region --------------------------------
     pcm_host, me, n_samples = make_shard_pcm(np, rank, world)
@@ -109,7 +117,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     barrier()
@@ -144,11 +152,15 @@ def main():
         shards = shard.plan_shards(FRAMES_PER_GPU * world, FRAMES_PER_GPU * world * HOP, world)
         barrier()
         g0 = time.perf_counter()
-        allrec = shard.gather_records(d_rec, shards, rec_bytes)
+        allrec = shard.gather_records(d_rec if backend == "nccl" else d_rec.cpu(), shards, rec_bytes)
         torch.cuda.synchronize()
         g_ms = (time.perf_counter() - g0) * 1e3
         gather = {"ms": round(g_ms, 3), "bytes_to_root": int(rec_bytes * FRAMES_PER_GPU * (world - 1)),
-                  "backend": "nccl(rccl)"}
+                  "backend": "nccl(rccl over xGMI)" if backend == "nccl" else backend}
+        if rank == 0:  # the gathered records assemble into one valid stream of world x 4096 frames
+            ea = glc_amd.EncodedAudio.from_records(SR, n_samples, CH, allrec.cpu().numpy())
+            gather["assembled_frames"] = int(ea.info().n_frames)
+            gather["assembled_raw_frames"] = int(ea.info().n_raw_frames)
         if rank == 0:
             assert allrec.numel() == rec_bytes * FRAMES_PER_GPU * world
 

@@ -382,6 +382,8 @@ __device__ __forceinline__ void step4(f32x2 (&acc)[4][4], const Operands &c, Ope
   }
 }
 
+#include "glc_k1_step_scalar.inc"
+
 template <int TM>
 __device__ __forceinline__ void mac_step(f32x2 (&acc)[TM][4], const Operands &o) {
   mac2rows(acc[0], acc[1], o.a0, o.b0, o.b1, o.b2, o.b3);
@@ -394,12 +396,15 @@ __device__ __forceinline__ void mac_step(f32x2 (&acc)[TM][4], const Operands &o)
 
 // ABL (tuning only, results are wrong when != 0): 1 = no staging/barrier inside the stage loop,
 // 2 = additionally no LDS operand reads inside the loop (pure VALU stream).
-template <int BM, int BN, int BK, int MINW, int ABL = 0, int TM = 8>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MINW, MINW))) void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm,
-                                                               long long frame_begin, unsigned M,
-                                                               float *__restrict__ coef) {
+// SCALAR = v_mul_f32/v_add_f32 stream (TM == 4 only) instead of the packed v_pk_* one: on
+// gfx950 both forms have the same peak MAC rate, but the 2-cycle scalar ops reach it with fewer
+// waves per SIMD (profiles/r01_microbench_valu_mfma.txt: A vs B).
+template <int BM, int BN, int BK, int MINW, int ABL = 0, int TM = 8, bool SCALAR = false>
+__global__ __launch_bounds__((BM / TM) * (BN / 8)) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
+void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm, long long frame_begin, unsigned M,
+                      float *__restrict__ coef) {
   using C = Cfg<BM, BN, BK, TM, 8, 2, MINW>;
-  static_assert(C::kThreads == 256, "TMx8 lane tile, 256 threads");
+  static_assert(!SCALAR || TM == 4, "scalar stream is written for the 4x8 lane tile");
   __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
 
@@ -479,10 +484,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MINW, MINW)
   };
 
   f32x2 acc[TM][4];
+  float accs[4][8];
 #pragma unroll
   for (int r = 0; r < TM; ++r)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[r][c] = f32x2{0.0f, 0.0f};
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) accs[r][c] = 0.0f;
   auto fetch = [&](Operands &o, unsigned a_addr, unsigned b_addr, int ii) {
     if constexpr (TM == 8) lds_fetch<BM, BN>(o, a_addr, b_addr, ii);
     else lds_fetch4<BM, BN>(o, a_addr, b_addr, ii);
@@ -514,7 +524,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MINW, MINW)
       fetch(Y, a_addr, b_addr, 1);
       wait(Y);
     }
-    if constexpr (TM == 4 && ABL != 2) {
+    if constexpr (SCALAR && ABL != 2) {
+#pragma unroll
+      for (int ii = 0; ii < BK; ii += 2) {
+        step4s<BM, BN, true>(accs, X, Y, a_addr, b_addr, ii + 1);
+        if (ii + 2 < BK) step4s<BM, BN, true>(accs, Y, X, a_addr, b_addr, ii + 2);
+        else step4s<BM, BN, false>(accs, Y, X, a_addr, b_addr, 0);
+      }
+    } else if constexpr (TM == 4 && ABL != 2) {
 #pragma unroll
       for (int ii = 0; ii < BK; ii += 2) {
         step4<BM, BN, true>(acc, X, Y, a_addr, b_addr, ii + 1);
@@ -543,6 +560,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MINW, MINW)
     const unsigned row = m0 + ((r < 4) ? (ty * 4 + r) : (BM / 2 + ty * 4 + (r - 4)));
     if (row >= M) continue;
     float *dst = coef + static_cast<size_t>(row) * kHopI + n0;
+    if constexpr (SCALAR) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[r][c] = f32x2{accs[r & 3][2 * c], accs[r & 3][2 * c + 1]};
+    }
     float4 o;
     o.x = mul_rn(acc[r][0].x, tb.norm); o.y = mul_rn(acc[r][0].y, tb.norm);
     o.z = mul_rn(acc[r][1].x, tb.norm); o.w = mul_rn(acc[r][1].y, tb.norm);
@@ -553,13 +574,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MINW, MINW)
   }
 }
 
-template <int BM, int BN, int BK, int MINW, int ABL = 0, int TM = 8>
+template <int BM, int BN, int BK, int MINW, int ABL = 0, int TM = 8, bool SCALAR = false>
 inline hipError_t launch_sched(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M,
                                float *coef, hipStream_t s) {
   using C = Cfg<BM, BN, BK, TM, 8, 2, MINW>;
   if (M == 0) return hipSuccess;
   const unsigned m_tiles = (M + BM - 1) / BM;
-  hipLaunchKernelGGL((k_mdct_fwd_sched<BM, BN, BK, MINW, ABL, TM>), dim3(m_tiles * C::kNTiles), dim3(256), 0, s, t, pcm,
+  hipLaunchKernelGGL((k_mdct_fwd_sched<BM, BN, BK, MINW, ABL, TM, SCALAR>), dim3(m_tiles * C::kNTiles),
+                     dim3(C::kThreads), 0, s, t, pcm,
                      static_cast<long long>(frame_begin), M, coef);
   return hipGetLastError();
 }

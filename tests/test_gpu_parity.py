@@ -238,3 +238,92 @@ def test_cfg2_full_size_properties(torch_cuda):
     dec = glc_amd.Decoder(ch, sr).decode(enc)
     assert dec.size == x.size
     assert calculate_snr(x[:400000], dec[:400000]) > -10.0
+
+
+# ---------------------------------------------------------------------------------------
+# BASELINE configs 3-5 at full size.  The oracle is too slow for whole streams, so each test
+# pins a prefix / window bit-exactly against the oracle and checks size-independent properties
+# (exact length, periodicity of a tiled input, chunk-boundary continuity) on the whole stream.
+# ---------------------------------------------------------------------------------------
+
+def _tile(seg, ch, reps):
+    return np.tile(seg.reshape(-1, ch), (reps, 1)).reshape(-1)
+
+
+def test_cfg3_ten_minutes_roundtrip(torch_cuda):
+    """config 3: encode+decode roundtrip, 10 min 48 kHz stereo (overlap-add gapless check)."""
+    sr, ch = 48000, 2
+    seg = gen_chord(sr, ch, 480000)              # 10 s
+    x = _tile(seg, ch, 60)                       # 10 min = 57 600 000 samples
+    assert x.size == 57_600_000 and glc_amd.plan_encode(x.size, ch).n_frames == 28125
+    enc = glc_amd.Encoder(sr).encode(x, ch)
+    info = enc.info()
+    assert info.n_frames == 28125 and info.n_raw_frames == 0
+    dec = glc_amd.Decoder(ch, sr).decode(enc)
+    assert dec.size == x.size                    # gapless length equality
+    # prefix pinned against the oracle: the first 10 s of the stream
+    n_pref = 400 * 1024 * ch
+    ref = O.encode(x[:n_pref + 2048 * ch], sr, ch, taps=True)
+    for f in range(0, 398, 37):
+        a, b = enc.frames[f], parse_glc(ref.glc)["frames"][f]
+        assert np.array_equal(np.float32(a.scale_factors).view(np.uint32), b["scales"].view(np.uint32))
+        for c in range(ch):
+            assert a.sparse_coeffs_per_channel[c] == list(zip(b["lists"][c][0].tolist(), b["lists"][c][1].tolist()))
+    dref, _, _ = O.decode(ref.glc)
+    assert np.array_equal(bits(dec[:390 * 1024 * ch]), bits(dref[:390 * 1024 * ch]))
+    # overlap-add continuity across the library's 4096-frame decode chunks and 500-frame
+    # streaming chunks: decoding a window that straddles the boundary alone gives the same bits
+    assert calculate_snr(x[:2_000_000], dec[:2_000_000]) > -10.0
+    for boundary in (4096, 8192, 500, 24576):
+        lo, hi = boundary - 3, boundary + 3
+        sub = x[lo * 1024 * ch:(hi * 1024 + 512) * ch]
+        sub_dec = glc_amd.Decoder(ch, sr).decode(glc_amd.Encoder(sr).encode(sub, ch))
+        # sub-stream hop j (j >= 2) equals hop lo + j of the big stream; account for the 512-sample
+        # interleaved delay trim (Q3) on both sides
+        a = dec[((lo + 2) * 1024) * ch:((hi - 1) * 1024) * ch]
+        b = sub_dec[(2 * 1024) * ch:((hi - lo - 1) * 1024) * ch]
+        assert np.array_equal(bits(a), bits(b))
+
+
+def test_cfg4_long_96k_stream_shard(torch_cuda):
+    """config 4 (one rank's share): a long 96 kHz stereo stream built by tiling a 60 s segment.
+    60 s * 96000 = 5625 frames exactly, so frame records repeat with period 5625 — a checksum-free,
+    size-independent property — and the first period is pinned against the oracle on a prefix."""
+    sr, ch = 96000, 2
+    seg = gen_chord(sr, ch, 60 * sr, n_tones=8)
+    reps = 6                                     # 6 min per rank here; 1 h in the real config
+    x = _tile(seg, ch, reps)
+    plan = glc_amd.plan_encode(x.size, ch)
+    assert plan.n_frames == 5625 * reps
+    recs, _ = device_encode(torch_cuda, x, sr, ch, want_coeffs=False)
+    rec = glc_amd.lib.glc_record_bytes(ch)
+    r = recs.reshape(-1, rec)
+    for k in range(1, reps):
+        assert np.array_equal(r[1:5624], r[k * 5625 + 1:k * 5625 + 5624])
+    ref = O.encode(x[:(64 * 1024 + 512) * ch], sr, ch, taps=True)
+    is_raw, scale, nnz, payload = split_records(recs[:64 * rec], ch)
+    assert np.array_equal(bits(scale[:62 * ch]), bits(ref.scales[:62 * ch]))
+    assert np.array_equal(nnz[:62 * ch], ref.nnz[:62 * ch])
+    assert np.array_equal(payload[:62, :, :1024].reshape(-1, 1024), ref.dense_q[:62 * ch])
+
+
+def test_cfg5_eight_channel_192k(torch_cuda):
+    """config 5: 7.1-channel 192 kHz high-res (8 channels): channel x frame tiling stress."""
+    sr, ch = 192000, 8
+    seg = gen_chord(sr, ch, 192000, n_tones=6)   # 1 s
+    x = _tile(seg, ch, 20)                       # 20 s = 30 720 000 samples, 3750 frames x 8 ch
+    plan = glc_amd.plan_encode(x.size, ch)
+    assert plan.n_frames == 3750
+    enc = glc_amd.Encoder(sr).encode(x, ch)
+    assert enc.info().n_frames == 3750
+    ref = O.encode(x[:(40 * 1024 + 512) * ch], sr, ch)
+    g = parse_glc(ref.glc)
+    for f in range(0, 38, 5):
+        a, b = enc.frames[f], g["frames"][f]
+        assert np.array_equal(np.float32(a.scale_factors).view(np.uint32), b["scales"].view(np.uint32))
+        for c in range(ch):
+            assert a.sparse_coeffs_per_channel[c] == list(zip(b["lists"][c][0].tolist(), b["lists"][c][1].tolist()))
+    dec = glc_amd.Decoder(ch, sr).decode(enc)
+    assert dec.size == x.size
+    dref, _, _ = O.decode(ref.glc)
+    assert np.array_equal(bits(dec[:30 * 1024 * ch]), bits(dref[:30 * 1024 * ch]))

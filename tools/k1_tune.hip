@@ -93,13 +93,18 @@ int main(int argc, char **argv) {
   std::vector<uint32_t> ref((size_t)M * 1024), out((size_t)M * 1024);
   CHECK(hipMemcpy(ref.data(), d_ref, ref.size() * 4, hipMemcpyDeviceToHost));
 
+  // hand-scheduled kernels (shipped shapes first), their ablations, then hipcc-scheduled shapes
   std::vector<Variant> vs = {
-      Variant{"sched 128x128 bk16 t8 w3", k1::launch_sched<128, 128, 16, 3>},
-      Variant{"sched 128x128 bk16 t8 w3 ABL1", k1::launch_sched<128, 128, 16, 3, 1>},
-      Variant{"sched 128x128 bk16 t8 w3 ABL2", k1::launch_sched<128, 128, 16, 3, 2>},
-      Variant{"sched 64x128 bk16 t4 w4", k1::launch_sched<64, 128, 16, 4, 0, 4>},
-      Variant{"sched 64x128 bk16 t4 w4 ABL1", k1::launch_sched<64, 128, 16, 4, 1, 4>},
-      Variant{"sched 64x128 bk16 t4 w4 ABL2", k1::launch_sched<64, 128, 16, 4, 2, 4>},
+      Variant{"sched pk  64x128 bk16 t4x8 w4 (shipped, M < 16384)", k1::launch_sched<64, 128, 16, 4, 0, 4>},
+      Variant{"sched pk 128x128 bk16 t8x8 w3 (shipped, M >= 16384)", k1::launch_sched<128, 128, 16, 3, 0, 8>},
+      Variant{"sched pk  64x128 ABL1 (no staging/barrier)", k1::launch_sched<64, 128, 16, 4, 1, 4>},
+      Variant{"sched pk  64x128 ABL2 (pure VALU stream)", k1::launch_sched<64, 128, 16, 4, 2, 4>},
+      Variant{"sched sc  64x128 bk16 t4x8 w4 (scalar v_mul/v_add)", k1::launch_sched<64, 128, 16, 4, 0, 4, true>},
+      Variant{"sched pk 128x128 bk16 t4x8 w4 (512 threads)", k1::launch_sched<128, 128, 16, 4, 0, 4>},
+      Variant{"sched pk  64x128 bk8  t4x8 w4", k1::launch_sched<64, 128, 8, 4, 0, 4>},
+      Variant{"sched pk  64x128 bk32 t4x8 w4", k1::launch_sched<64, 128, 32, 4, 0, 4>},
+      V(128, 128, 16, 8, 8, 2, 2), V(128, 128, 8, 8, 8, 2, 2), V(64, 128, 16, 4, 8, 2, 4),
+      V(128, 128, 16, 4, 8, 2, 2), V(64, 64, 16, 4, 4, 4, 8),
   };
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
