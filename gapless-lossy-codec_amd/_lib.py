@@ -77,6 +77,10 @@ SIGNATURES = {
     "glc_frame_raw": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "glc_ctx_tables": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp, _vp,
                                  C.POINTER(C.c_uint32)]),
+    "glc_wav_load": (C.c_int, [C.c_char_p, C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
+                               C.POINTER(C.c_uint16)]),
+    "glc_wav_save16": (C.c_int, [C.c_char_p, _vp, C.c_uint64, C.c_uint32, C.c_uint16]),
+    "glc_free": (None, [_vp]),
     "glc_version": (C.c_char_p, []),
 }
 

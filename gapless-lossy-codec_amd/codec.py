@@ -286,3 +286,24 @@ def load_encoded(path) -> EncodedAudio:
     out = C.c_void_p()
     check(lib.glc_load(str(path).encode(), C.byref(out)))
     return EncodedAudio(out.value)
+
+
+def load_wav(path):
+    """audio::load_wav (src/audio.rs:39-64) -> (samples f32 interleaved, sample_rate, channels)."""
+    ptr = C.c_void_p()
+    n = C.c_uint64()
+    sr = C.c_uint32()
+    ch = C.c_uint16()
+    check(lib.glc_wav_load(str(path).encode(), C.byref(ptr), C.byref(n), C.byref(sr), C.byref(ch)))
+    try:
+        out = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(n.value,)).copy() \
+            if n.value else np.empty(0, np.float32)
+    finally:
+        lib.glc_free(ptr)
+    return out, sr.value, ch.value
+
+
+def export_to_wav(path, samples, sample_rate: int, channels: int) -> None:
+    """audio::export_to_wav (src/audio.rs:100-132): 16-bit PCM."""
+    s = np.ascontiguousarray(samples, np.float32).reshape(-1)
+    check(lib.glc_wav_save16(str(path).encode(), s.ctypes.data_as(C.c_void_p), s.size, sample_rate, channels))

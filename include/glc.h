@@ -178,6 +178,18 @@ int glc_frame_scale(const glc_frames *f, uint64_t frame, uint32_t channel, float
 /* EncodedFrame.raw_pcm: copies up to cap samples, returns the length through n. */
 int glc_frame_raw(const glc_frames *f, uint64_t frame, int16_t *pcm, uint64_t cap, uint64_t *n);
 
+/* ---- WAV file I/O twin (src/audio.rs; host only, no device) ---------------------------------- */
+
+/* load_wav src/audio.rs:39-64: RIFF/WAVE PCM (8/16/24/32-bit integer -> s / 2^(bits-1), 8-bit is
+ * unsigned in the file) and 32-bit IEEE float (passed through), incl. WAVE_FORMAT_EXTENSIBLE.
+ * Returns a malloc'd interleaved buffer; release it with glc_free. */
+int glc_wav_load(const char *path, float **samples, uint64_t *n_samples, uint32_t *sample_rate,
+                 uint16_t *channels);
+/* export_to_wav src/audio.rs:100-132: 16-bit PCM, (s * 32767).clamp(-32768, 32767) as i16. */
+int glc_wav_save16(const char *path, const float *samples, uint64_t n_samples, uint32_t sample_rate,
+                   uint16_t channels);
+void glc_free(void *p);
+
 /* ---- tables (for inspection / parity tests) ---------------------------------------------- */
 
 /* Copies of the host tables of a context: MdctTables.cos_table [1024*2048] (row k), window
