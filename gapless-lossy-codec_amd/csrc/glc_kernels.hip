@@ -49,98 +49,138 @@ __device__ __forceinline__ short sat_i16(float x) {
 // K1 (forward MDCT) lives in glc_mdct_fwd.hpp.
 
 // ------------------------------------------------------------------------------------------
-// K2: one wavefront per frame-channel row.  scale = max|c| (order-free), per-band sequential
-// sum of squares (one lane per critical band: the reference's summation order is kept), masking
-// thresholds, noise floor, quantiser.  Emits the dense i16 row + {scale, nnz} into the record.
+// K2: scale, masking thresholds, quantiser.  A wavefront owns 4 consecutive frame-channel rows.
+//   phase 1  16 coefficients per lane and row: max|c| by shuffle (order-free), squares to LDS
+//   phase 2  band sums in the reference's ascending order (src/codec.rs:212-214): lane l sums
+//            bands (l & 15), +16, +32, +48 of row l >> 4, so the long last band (683 bins at
+//            48 kHz) of the 4 rows runs in 4 lanes side by side instead of one lane per wave
+//   phase 3  thresholds, noise floor, quantiser; dense i16 row + {scale, nnz} into the record
 // ------------------------------------------------------------------------------------------
+constexpr int kQRows = 4;  // rows per wave
+
 __global__ __launch_bounds__(256) void k_quantize(DeviceTables tb, const float *__restrict__ coef,
                                                    unsigned M, unsigned ch, unsigned long long rec_bytes,
                                                    unsigned long long hdr_bytes,
                                                    unsigned char *__restrict__ records) {
-  __shared__ __attribute__((aligned(16))) float srow[4][kHopI];
-  __shared__ float sbase[4][64];
+  __shared__ __attribute__((aligned(16))) float ssq[4][kQRows][kHopI];  // 64 KiB
+  __shared__ float sbase[4][kQRows][64];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const unsigned m = blockIdx.x * 4 + w;
-  const bool live = m < M;
+  const unsigned m0 = (blockIdx.x * 4 + w) * kQRows;
 
-  float4 c4[4];
-  float amax = 0.0f;
-  if (live) {
-    const float4 *src = reinterpret_cast<const float4 *>(coef + static_cast<size_t>(m) * kHopI);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      c4[j] = src[lane + 64 * j];
-      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(c4[j].x), fabsf(c4[j].y)), fmaxf(fabsf(c4[j].z), fabsf(c4[j].w))));
-      // squares are formed in parallel (each is one rounding, order-free); only the SUM below
-      // has to follow the reference's ascending order (src/codec.rs:212-214)
-      float4 sq;
-      sq.x = mul_rn(c4[j].x, c4[j].x); sq.y = mul_rn(c4[j].y, c4[j].y);
-      sq.z = mul_rn(c4[j].z, c4[j].z); sq.w = mul_rn(c4[j].w, c4[j].w);
-      *reinterpret_cast<float4 *>(&srow[w][(lane + 64 * j) * 4]) = sq;
-    }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
-  const float scale = fmaxf(amax, 1e-10f);  // :488 (and global_max at :198, :278)
-  __syncthreads();
-
-  if (live && lane < static_cast<int>(tb.n_bands)) {
-    const unsigned lo = tb.edges[lane], hi = tb.edges[lane + 1];
-    const float *sq = srow[w];
-    float ss = 0.0f;
-    unsigned i = lo;
-    for (; i + 8 <= hi; i += 8) {  // 8 LDS reads in flight, then the 8 dependent adds
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = sq[i + j];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ss = add_rn(ss, v[j]);
-    }
-    for (; i < hi; ++i) ss = add_rn(ss, sq[i]);
-    const float energy = sqrtf(ss / tb.band_len[lane]);                       // :214-215
-    const float base = mul_rn(mul_rn(mul_rn(energy, 0.01f), tb.cf), tb.band_pf[lane]);  // :223
-    sbase[w][lane] = base;
-  }
-  __syncthreads();
-  if (!live) return;
-
-  const unsigned frame = m / ch, c = m % ch;
-  unsigned char *rec = records + static_cast<size_t>(frame) * rec_bytes;
-  short *qrow = reinterpret_cast<short *>(rec + hdr_bytes) + static_cast<size_t>(c) * kFrameI;
-
-  const float nfl = mul_rn(tb.noise_floor, scale);  // :277
-  const float peak_gate = mul_rn(scale, 0.3f);      // global_max * 0.3, :232
-  const float peak_cap = mul_rn(scale, 0.05f);      // global_max * 0.05, :234
-  unsigned cnt = 0;
+  // per-lane constants of the 16 bins this lane owns (the same bins in every row)
+  float4 indiv4[4];
+  unsigned short bo[4][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int k0 = (lane + 64 * j) * 4;
-    const float cv[4] = {c4[j].x, c4[j].y, c4[j].z, c4[j].w};
-    short qv[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int k = k0 + e;
-      const float a = fabsf(cv[e]);
-      float t = mul_rn(sbase[w][tb.band_of[k]], tb.indiv[k]);  // :228-229
-      if (a > peak_gate) t = fminf(t, peak_cap);               // :232-235
-      const float thr = mul_rn(t, scale);                      // :288
-      short q = 0;
-      if (a > nfl && a > thr) {                                // :291
-        const float normalized = cv[e] / scale;                // :299 (IEEE divide)
-        q = sat_i16(roundf(mul_rn(normalized, 32768.0f)));     // :300-301
-      }
-      qv[e] = q;
-      cnt += (q != 0);
-    }
-    short4 pk;
-    pk.x = qv[0]; pk.y = qv[1]; pk.z = qv[2]; pk.w = qv[3];
-    *reinterpret_cast<short4 *>(qrow + k0) = pk;
+    indiv4[j] = *reinterpret_cast<const float4 *>(tb.indiv + k0);
+    const ushort4 b4 = *reinterpret_cast<const ushort4 *>(tb.band_of + k0);
+    bo[j][0] = b4.x; bo[j][1] = b4.y; bo[j][2] = b4.z; bo[j][3] = b4.w;
   }
+
+  float4 c4[kQRows][4];
+  float scale[kQRows];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-  if (lane == 0) {
-    *reinterpret_cast<float *>(rec + 8 + 8 * c) = scale;
-    *reinterpret_cast<unsigned *>(rec + 8 + 8 * c + 4) = cnt;
+  for (int r = 0; r < kQRows; ++r) {
+    const unsigned m = m0 + r;
+    float amax = 0.0f;
+    if (m < M) {
+      const float4 *src = reinterpret_cast<const float4 *>(coef + static_cast<size_t>(m) * kHopI);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 v = src[lane + 64 * j];
+        c4[r][j] = v;
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        float4 sq;  // each square is one rounding, order-free; only the SUM is ordered
+        sq.x = mul_rn(v.x, v.x); sq.y = mul_rn(v.y, v.y); sq.z = mul_rn(v.z, v.z); sq.w = mul_rn(v.w, v.w);
+        *reinterpret_cast<float4 *>(&ssq[w][r][(lane + 64 * j) * 4]) = sq;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c4[r][j] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    scale[r] = fmaxf(amax, 1e-10f);  // :488 (and global_max at :198, :278)
+  }
+  __syncthreads();
+
+  {
+    const int r = lane >> 4;
+    if (m0 + r < M) {
+      const float *sq = ssq[w][r];
+      for (unsigned b = lane & 15; b < tb.n_bands; b += 16) {
+        const unsigned lo = tb.edges[b], hi = tb.edges[b + 1];
+        float ss = 0.0f;
+        unsigned i = lo;
+        if (i + 8 <= hi) {
+          // software pipeline: the next 8 LDS reads are in flight while the current 8 adds (a
+          // dependent chain, the reference's order) execute
+          float v[8], nv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = sq[i + j];
+          for (; i + 16 <= hi; i += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) nv[j] = sq[i + 8 + j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss = add_rn(ss, v[j]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = nv[j];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ss = add_rn(ss, v[j]);
+          i += 8;
+        }
+        for (; i < hi; ++i) ss = add_rn(ss, sq[i]);
+        const float energy = sqrtf(ss / tb.band_len[b]);                                  // :214-215
+        sbase[w][r][b] = mul_rn(mul_rn(mul_rn(energy, 0.01f), tb.cf), tb.band_pf[b]);      // :223
+      }
+    }
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int r = 0; r < kQRows; ++r) {
+    const unsigned m = m0 + r;
+    if (m >= M) break;
+    const unsigned frame = m / ch, c = m % ch;
+    unsigned char *rec = records + static_cast<size_t>(frame) * rec_bytes;
+    short *qrow = reinterpret_cast<short *>(rec + hdr_bytes) + static_cast<size_t>(c) * kFrameI;
+    const float sc = scale[r];
+    const float nfl = mul_rn(tb.noise_floor, sc);  // :277
+    const float peak_gate = mul_rn(sc, 0.3f);      // global_max * 0.3, :232
+    const float peak_cap = mul_rn(sc, 0.05f);      // global_max * 0.05, :234
+    unsigned cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k0 = (lane + 64 * j) * 4;
+      const float cv[4] = {c4[r][j].x, c4[r][j].y, c4[r][j].z, c4[r][j].w};
+      const float iv[4] = {indiv4[j].x, indiv4[j].y, indiv4[j].z, indiv4[j].w};
+      short qv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = fabsf(cv[e]);
+        float t = mul_rn(sbase[w][r][bo[j][e]], iv[e]);             // :228-229
+        if (a > peak_gate) t = fminf(t, peak_cap);                  // :232-235
+        const float thr = mul_rn(t, sc);                            // :288
+        short q = 0;
+        if (a > nfl && a > thr) {                                   // :291
+          const float normalized = cv[e] / sc;                      // :299 (IEEE divide)
+          q = sat_i16(roundf(mul_rn(normalized, 32768.0f)));        // :300-301
+        }
+        qv[e] = q;
+        cnt += (q != 0);
+      }
+      short4 pk;
+      pk.x = qv[0]; pk.y = qv[1]; pk.z = qv[2]; pk.w = qv[3];
+      *reinterpret_cast<short4 *>(qrow + k0) = pk;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (lane == 0) {
+      *reinterpret_cast<float *>(rec + 8 + 8 * c) = sc;
+      *reinterpret_cast<unsigned *>(rec + 8 + 8 * c + 4) = cnt;
+    }
   }
 }
 
@@ -294,7 +334,8 @@ hipError_t launch_quantize(const DeviceTables &t, const float *coef, uint32_t M,
   if (M == 0) return hipSuccess;
   const unsigned long long hdr = ((8ull + 8ull * ch) + 15ull) & ~15ull;
   const unsigned long long rec = hdr + 2ull * kFrameI * ch;
-  hipLaunchKernelGGL(k_quantize, dim3((M + 3) / 4), dim3(256), 0, s, t, coef, M, ch, rec, hdr, records);
+  hipLaunchKernelGGL(k_quantize, dim3((M + 4 * kQRows - 1) / (4 * kQRows)), dim3(256), 0, s, t, coef, M, ch, rec, hdr,
+                     records);
   return hipGetLastError();
 }
 
