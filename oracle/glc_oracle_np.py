@@ -140,7 +140,7 @@ def thresholds_rows(c: np.ndarray, w: np.ndarray, edges: np.ndarray):
     """src/codec.rs:188-240 (vectorised over rows, sequential inside each band)."""
     M = c.shape[0]
     thr = np.zeros((M, HOP), F32)
-    gmax = np.maximum(np.abs(c).max(axis=1), F32(1e-10)).astype(F32)
+    gmax = np.fmax(np.fmax.reduce(np.abs(c), axis=1, initial=F32(0.0)), F32(1e-10)).astype(F32)  # f32::max ignores NaN
     cf = max(F32(1.0) - F32(0.7), F32(0.01))
     for b in range(len(edges) - 1):
         s, e = int(edges[b]), min(int(edges[b + 1]), HOP)
@@ -160,7 +160,7 @@ def thresholds_rows(c: np.ndarray, w: np.ndarray, edges: np.ndarray):
             indiv = F32(1.0) / max(w[i], F32(0.1))
             t = (base * indiv).astype(F32)
             peak = np.abs(c[:, i]) > gmax * F32(0.3)
-            t = np.where(peak, np.minimum(t, gmax * F32(0.05)), t)
+            t = np.where(peak, np.fmin(t, gmax * F32(0.05)), t)  # f32::min ignores NaN
             thr[:, i] = t
     return thr, gmax
 
@@ -187,11 +187,13 @@ def encode(pcm: np.ndarray, sr: int, ch: int):
     weights, edges = perceptual(sr)
     rows, nf, P, L = windowed_rows(pcm, ch, w)
     c = mdct_rows(rows, T, norm)
-    scale = np.maximum(np.abs(c).max(axis=1), F32(1e-10)).astype(F32)
+    scale = np.fmax(np.fmax.reduce(np.abs(c), axis=1, initial=F32(0.0)), F32(1e-10)).astype(F32)  # :488, NaN-ignoring
     thr, _ = thresholds_rows(c, weights, edges)
     q = quantise_rows(c, scale, thr)
     nnz = (q != 0).sum(axis=1).astype(np.uint32)
-    raw = np.clip((rows * F32(32767.0)).astype(F32), -32768.0, 32767.0).astype(np.int16)
+    with np.errstate(invalid="ignore"):
+        rv = np.clip((rows * F32(32767.0)).astype(F32), -32768.0, 32767.0)
+    raw = np.where(np.isnan(rv), F32(0.0), rv).astype(np.int16)  # `NaN as i16` == 0 in Rust
     is_raw = np.zeros(nf, np.uint8)
     out = [struct.pack("<IHQ", sr, ch, pcm.size), struct.pack("<Q", nf)]
     for f in range(nf):

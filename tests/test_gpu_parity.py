@@ -81,7 +81,36 @@ CASES = [
     ("quiet_48k_stereo", lambda: gen_chord(48000, 2, 6000, amp=1e-12), 48000, 2),
     ("silence_48k_stereo", lambda: np.zeros(2 * 5000, np.float32), 48000, 2),
     ("min_len_mono", lambda: gen_chord(48000, 1, 513), 48000, 1),
+    ("denormal_stereo", lambda: _special("denormal"), 44100, 2),
+    ("huge_and_clipping_mono", lambda: _special("huge"), 48000, 1),
+    ("nan_inf_stereo", lambda: _special("nan"), 48000, 2),
+    ("impulses_5ch", lambda: _special("impulse"), 96000, 5),
 ]
+
+
+def _special(kind):
+    """Inputs outside the nominal [-1, 1] PCM range: the GPU path must still agree bit for bit."""
+    rng = np.random.RandomState(11)
+    if kind == "denormal":   # f32 subnormals in, subnormal products and sums (denorm mode must be IEEE)
+        x = gen_chord(44100, 2, 6000, amp=0.2)
+        x[2000:9000] = (rng.uniform(-1, 1, 7000) * 1e-39).astype(np.float32)
+        x[9000:9800] = np.float32(1e-45) * rng.randint(-3, 4, 800).astype(np.float32)
+        return x
+    if kind == "huge":       # far beyond full scale: quantiser clamps, raw plane saturates
+        x = gen_chord(48000, 1, 7000, amp=0.3)
+        x[1000:1400] *= np.float32(1e6)
+        x[3000:3003] = np.float32([3.0e38, -3.0e38, 1.0e30])
+        return x
+    if kind == "nan":        # NaN / Inf propagate exactly like the reference's f32 arithmetic
+        x = gen_chord(48000, 2, 5000, amp=0.2)
+        x[1501] = np.nan
+        x[4002] = np.inf
+        x[7003] = -np.inf
+        return x
+    x = np.zeros(4000 * 5, np.float32)   # isolated unit impulses, one per channel
+    for c in range(5):
+        x[(700 + 411 * c) * 5 + c] = 1.0 if c % 2 == 0 else -1.0
+    return x
 
 
 @pytest.mark.parametrize("name,make,sr,ch", CASES, ids=[c[0] for c in CASES])

@@ -63,7 +63,16 @@ CASES = [
     ("noise_44k_stereo", lambda: gen_noise(44100, 2, 0.5, 12345), 44100, 2),
     ("sweep_48k_mono", lambda: gen_tone("sweep", 100.0, 48000, 1, 1.0, 10000.0), 48000, 1),
     ("square_44k_mono", lambda: gen_tone("square", 1000.0, 44100, 1, 0.5), 44100, 1),
+    ("denormals", lambda: _special("denormal"), 44100, 2),
+    ("huge_values", lambda: _special("huge"), 48000, 1),
+    ("nan_inf", lambda: _special("nan"), 48000, 2),
+    ("impulses_5ch", lambda: _special("impulse"), 96000, 5),
 ]
+
+
+def _special(kind):
+    from test_gpu_parity import _special as sp
+    return sp(kind)
 
 
 @pytest.mark.parametrize("name,make,sr,ch", CASES, ids=[c[0] for c in CASES])
