@@ -58,6 +58,7 @@ SIGNATURES = {
                                           C.c_uint64, C.c_uint64, _vp]),
     "glc_frames_from_records": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint16, _vp, C.c_uint64,
                                           C.POINTER(_vp)]),
+    "glc_frames_from_device_records": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint16, C.POINTER(_vp)]),
     "glc_decoded_len": (C.c_uint64, [_vp]),
     "glc_decode": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "glc_decode_stream_begin": (C.c_int, [_vp, _vp]),

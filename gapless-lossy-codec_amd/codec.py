@@ -236,6 +236,13 @@ class Encoder(_Ctx):
                                           frame_begin, frame_end, C.c_void_p(d_records),
                                           C.c_void_p(d_coeffs) if d_coeffs else None), self._h)
 
+    def frames_from_device_records(self, d_records: int, n_frames: int, n_samples: int, channels: int) -> EncodedAudio:
+        """EncodedAudio from records still on this context's device (device-side compaction)."""
+        out = C.c_void_p()
+        check(lib.glc_frames_from_device_records(self._h, C.c_void_p(d_records), n_frames, n_samples, channels,
+                                                 C.byref(out)), self._h)
+        return EncodedAudio(out.value)
+
     def mdct_forward_device(self, d_pcm: int, t0: int, t_count: int, n_samples: int, channels: int,
                             frame_begin: int, frame_end: int, d_coeffs: int) -> None:
         """Window + mdct_block only (src/codec.rs:476-485) for a frame range, device-resident."""

@@ -63,12 +63,15 @@ struct glc_ctx {
   DevBuf records;    // staging for host-boundary encode
   DevBuf blocks;     // decode: windowed IMDCT blocks [(chunk+1)][ch][2048]
   DevBuf dec_meta;   // decode: pairs / offsets / scales / raw pool
+  DevBuf pack_meta;  // compaction: loc, blk, blk_raw, totals, scales, is_raw, row_off
+  DevBuf pack_pairs; // compaction: packed pairs
+  DevBuf pack_raw;   // compaction: raw planes
   std::string err;
-  // streaming decode state (glc_decode_stream_*)
-  std::vector<float> stream_pcm;
-  uint64_t stream_pos = 0;
-  uint32_t stream_ch = 0;
-  bool stream_open = false;
+  // decode session (decode_prepare / decode_chunk): device-resident sparse rows + position
+  glc::DecodeRows dec_rows{};
+  uint32_t dec_ch = 0;
+  uint64_t dec_frames = 0, dec_next = 0;
+  bool stream_open = false;  // glc_decode_stream_begin called, last chunk not yet delivered
 };
 
 namespace {
@@ -224,6 +227,9 @@ void glc_ctx_destroy(glc_ctx *ctx) {
   ctx->records.release();
   ctx->blocks.release();
   ctx->dec_meta.release();
+  ctx->pack_meta.release();
+  ctx->pack_pairs.release();
+  ctx->pack_raw.release();
   delete ctx;
 }
 
@@ -335,6 +341,114 @@ int glc_mdct_forward_device(glc_ctx *ctx, const float *d_pcm, uint64_t t0, uint6
   return GLC_OK;
 }
 
+int glc_frames_from_device_records(glc_ctx *ctx, const void *d_records, uint64_t n_frames,
+                                   uint64_t n_samples, uint16_t channels, glc_frames **out) {
+  if (!ctx || !d_records || !out) return fail(ctx, GLC_EINVAL, "glc_frames_from_device_records: null argument");
+  *out = nullptr;
+  const glc_plan plan = glc::plan_encode(n_samples, channels);
+  if (plan.n_frames == 0 || plan.n_frames != n_frames)
+    return fail(ctx, GLC_EINVAL, "glc_frames_from_device_records: record count does not match the stream length");
+  const uint32_t ch = channels;
+  const uint64_t M64 = n_frames * ch;
+  if (M64 > 0xFFFFFFFFull) return fail(ctx, GLC_EINVAL, "glc_frames_from_device_records: stream too long");
+  const uint32_t M = static_cast<uint32_t>(M64);
+  DeviceGuard guard(ctx->device);
+  const uint8_t *recs = static_cast<const uint8_t *>(d_records);
+
+  const size_t nblk = (M + 1023) / 1024;
+  size_t off = 0;
+  auto place = [&](size_t bytes) {
+    size_t at = off;
+    off = align_up(off + bytes, 256);
+    return at;
+  };
+  const size_t o_loc = place(static_cast<size_t>(M) * 4), o_blk = place(nblk * 8), o_blkr = place(nblk * 8);
+  const size_t o_tot = place(16), o_scale = place(static_cast<size_t>(M) * 4), o_raw = place(n_frames);
+  const size_t o_rowoff = place(static_cast<size_t>(M) * 8);
+  GLC_HIP(ctx, ctx->pack_meta.reserve(off));
+  uint8_t *mb = static_cast<uint8_t *>(ctx->pack_meta.p);
+  auto *d_loc = reinterpret_cast<uint32_t *>(mb + o_loc);
+  auto *d_blk = reinterpret_cast<uint64_t *>(mb + o_blk);
+  auto *d_blkr = reinterpret_cast<uint64_t *>(mb + o_blkr);
+  auto *d_tot = reinterpret_cast<uint64_t *>(mb + o_tot);
+  auto *d_scale = reinterpret_cast<float *>(mb + o_scale);
+  auto *d_israw = mb + o_raw;
+  auto *d_rowoff = reinterpret_cast<uint64_t *>(mb + o_rowoff);
+
+  GLC_HIP(ctx, glc::launch_pack_scan(recs, M, ch, d_loc, d_blk, d_blkr, d_tot, d_scale, d_israw, ctx->stream));
+  uint64_t totals[2] = {0, 0};
+  GLC_HIP(ctx, hipMemcpyAsync(totals, d_tot, 16, hipMemcpyDeviceToHost, ctx->stream));
+  GLC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // sizes are needed to size the payload buffers
+  const uint64_t n_pairs = totals[0], n_raw_rows = totals[1];
+  if (n_pairs > static_cast<uint64_t>(M) * glc::kHop || n_raw_rows > M || n_raw_rows % ch != 0)
+    return fail(ctx, GLC_EINVAL, "glc_frames_from_device_records: corrupt records");
+  GLC_HIP(ctx, ctx->pack_pairs.reserve(std::max<size_t>(n_pairs, 1) * 4));
+  GLC_HIP(ctx, ctx->pack_raw.reserve(std::max<size_t>(n_raw_rows, 1) * glc::kFrame * 2));
+  GLC_HIP(ctx, glc::launch_pack_rows(recs, M, ch, d_loc, d_blk, d_blkr, static_cast<uint32_t *>(ctx->pack_pairs.p),
+                                     d_rowoff, static_cast<int16_t *>(ctx->pack_raw.p), ctx->stream));
+
+  std::unique_ptr<glc_frames> F(new (std::nothrow) glc_frames);
+  if (!F) return fail(ctx, GLC_ENOMEM, "glc_frames_from_device_records: host allocation failed");
+  std::vector<uint64_t> row_off;
+  std::vector<float> row_scale;
+  try {
+    F->sample_rate = ctx->sample_rate;
+    F->channels = channels;
+    F->total_samples = n_samples;
+    F->encoder_delay = plan.encoder_delay;
+    F->padding = plan.padding;
+    F->original_length = n_samples;
+    F->n_frames = n_frames;
+    F->raw_tag.resize(n_frames);
+    F->pairs.resize(n_pairs);
+    F->raw.resize(n_raw_rows * glc::kFrame);
+    row_off.resize(M);
+    row_scale.resize(M);
+  } catch (const std::bad_alloc &) {
+    return fail(ctx, GLC_ENOMEM, "glc_frames_from_device_records: host allocation failed");
+  }
+  if (n_frames) GLC_HIP(ctx, hipMemcpyAsync(F->raw_tag.data(), d_israw, n_frames, hipMemcpyDeviceToHost, ctx->stream));
+  if (M) GLC_HIP(ctx, hipMemcpyAsync(row_off.data(), d_rowoff, static_cast<size_t>(M) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (M) GLC_HIP(ctx, hipMemcpyAsync(row_scale.data(), d_scale, static_cast<size_t>(M) * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (n_pairs) GLC_HIP(ctx, hipMemcpyAsync(F->pairs.data(), ctx->pack_pairs.p, n_pairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (n_raw_rows) GLC_HIP(ctx, hipMemcpyAsync(F->raw.data(), ctx->pack_raw.p, n_raw_rows * glc::kFrame * 2, hipMemcpyDeviceToHost, ctx->stream));
+  GLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+  // index vectors of EncodedAudio: raw frames have no lists / scales, compressed frames no raw_pcm
+  try {
+    F->list_begin.assign(n_frames + 1, 0);
+    F->scale_begin.assign(n_frames + 1, 0);
+    F->raw_begin.assign(n_frames + 1, 0);
+    const uint64_t n_comp_rows = static_cast<uint64_t>(M) - n_raw_rows;
+    F->list_off.clear();
+    F->list_off.reserve(n_comp_rows + 1);
+    F->scales.clear();
+    F->scales.reserve(n_comp_rows);
+    uint64_t raw_at = 0;
+    for (uint64_t f = 0; f < n_frames; ++f) {
+      if (F->raw_tag[f]) {
+        raw_at += static_cast<uint64_t>(glc::kFrame) * ch;
+      } else {
+        for (uint32_t c = 0; c < ch; ++c) {
+          F->list_off.push_back(row_off[f * ch + c]);
+          F->scales.push_back(row_scale[f * ch + c]);
+        }
+      }
+      F->list_begin[f + 1] = F->list_off.size();
+      F->scale_begin[f + 1] = F->scales.size();
+      F->raw_begin[f + 1] = raw_at;
+    }
+    F->list_off.push_back(n_pairs);
+    F->lists_canonical = true;  // ballot-packed in ascending k
+    if (raw_at != n_raw_rows * glc::kFrame)
+      return fail(ctx, GLC_EINVAL, "glc_frames_from_device_records: raw flag / raw row mismatch");
+  } catch (const std::bad_alloc &) {
+    return fail(ctx, GLC_ENOMEM, "glc_frames_from_device_records: host allocation failed");
+  }
+  *out = F.release();
+  return GLC_OK;
+}
+
 int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t channels,
                glc_frames **out) {
   if (!ctx || !pcm || !out) return fail(ctx, GLC_EINVAL, "glc_encode: null argument");
@@ -354,46 +468,38 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
   int rc = glc_encode_range_device(ctx, static_cast<const float *>(ctx->pcm.p), 0, t_count, n_samples,
                                    channels, 0, plan.n_frames, ctx->records.p, nullptr);
   if (rc != GLC_OK) return rc;
-  std::vector<uint8_t> host;
-  try {
-    host.resize(static_cast<size_t>(plan.n_frames) * rec);
-  } catch (const std::bad_alloc &) {
-    return fail(ctx, GLC_ENOMEM, "glc_encode: host allocation failed");
-  }
-  GLC_HIP(ctx, hipMemcpyAsync(host.data(), ctx->records.p, host.size(), hipMemcpyDeviceToHost, ctx->stream));
-  GLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  rc = glc_frames_from_records(ctx->sample_rate, n_samples, channels, host.data(), plan.n_frames, out);
-  if (rc != GLC_OK) ctx->err = glc_last_error(nullptr);
-  return rc;
+  // compact on the device; only pairs / scales / raw planes cross PCIe
+  return glc_frames_from_device_records(ctx, ctx->records.p, plan.n_frames, n_samples, channels, out);
 }
 
 // ------------------------------------------------------------------------------ decode
 
 namespace {
 
-// Decode everything to an un-trimmed interleaved buffer of (n_frames+1)*1024*ch samples on the
-// host (what decode_streaming emits in total, src/codec.rs:688-732).
-int decode_all(glc_ctx *ctx, const glc_frames *in, std::vector<float> &all) {
+// Upload the sparse representation of `in` and reset the overlap state: after this the stream
+// can be decoded front to back in chunks (decode_chunk).  Sparse lists are used as stored when
+// canonical (strictly ascending, idx < 1024 — what the encoder emits); other lists are
+// canonicalised on the host with the reference's dense-array semantics (last write wins,
+// idx >= 1024 ignored, src/codec.rs:659-665) and appended behind the stored pairs.
+int decode_prepare(glc_ctx *ctx, const glc_frames *in) {
   const uint32_t ch = in->channels;
   if (ch == 0) return fail(ctx, GLC_EINVAL, "glc_decode: header.channels == 0");
   const uint64_t nf = in->n_frames;
   const uint64_t M = nf * ch;
+  if (M > 0xFFFFFFFFull) return fail(ctx, GLC_EINVAL, "glc_decode: stream too long");
 
-  // Per-row metadata.  Sparse lists are used as stored when canonical (strictly ascending,
-  // idx < 1024 — what the encoder emits); otherwise they are canonicalised on the host with
-  // the reference's dense-array semantics (last write wins, idx >= 1024 ignored, :659-665).
-  std::vector<uint64_t> row_off(M + 1, 0), row_raw_len(M, 0);
+  std::vector<uint64_t> row_begin(M, 0), row_raw_len(M, 0);
+  std::vector<uint32_t> row_cnt(M, 0);
   std::vector<int64_t> row_raw(M, -1);
   std::vector<float> row_scale(M, 0.f);
-  std::vector<uint32_t> pairs;
-  pairs.reserve(in->pairs.size());
+  std::vector<uint32_t> extra;  // canonicalised copies of non-canonical lists
   std::vector<int32_t> dense;
+  const uint64_t n_stored = in->pairs.size();
   for (uint64_t f = 0; f < nf; ++f) {
     if (in->raw_tag[f]) {
       for (uint32_t c = 0; c < ch; ++c) {
         row_raw[f * ch + c] = static_cast<int64_t>(in->raw_begin[f]);
         row_raw_len[f * ch + c] = in->raw_begin[f + 1] - in->raw_begin[f];
-        row_off[f * ch + c + 1] = pairs.size();
       }
       continue;
     }
@@ -404,102 +510,116 @@ int decode_all(glc_ctx *ctx, const glc_frames *in, std::vector<float> &all) {
     for (uint32_t c = 0; c < ch; ++c) {
       const uint64_t a = in->list_off[l0 + c], b = in->list_off[l0 + c + 1];
       bool canonical = true;
-      int32_t last = -1;
-      for (uint64_t j = a; j < b; ++j) {
-        const int32_t k = static_cast<int32_t>(in->pairs[j] & 0xFFFFu);
-        if (k <= last || k >= static_cast<int32_t>(glc::kHop)) {
-          canonical = false;
-          break;
+      if (!in->lists_canonical) {
+        int32_t last = -1;
+        for (uint64_t j = a; j < b; ++j) {
+          const int32_t k = static_cast<int32_t>(in->pairs[j] & 0xFFFFu);
+          if (k <= last || k >= static_cast<int32_t>(glc::kHop)) {
+            canonical = false;
+            break;
+          }
+          last = k;
         }
-        last = k;
       }
+      const uint64_t m = f * ch + c;
       if (canonical) {
-        pairs.insert(pairs.end(), in->pairs.begin() + a, in->pairs.begin() + b);
+        row_begin[m] = a;
+        row_cnt[m] = static_cast<uint32_t>(b - a);
       } else {
         dense.assign(glc::kHop, INT32_MIN);
         for (uint64_t j = a; j < b; ++j) {
           const uint32_t k = in->pairs[j] & 0xFFFFu;
           if (k < glc::kHop) dense[k] = static_cast<int16_t>(in->pairs[j] >> 16);
         }
+        row_begin[m] = n_stored + extra.size();
         // a stored q == 0 dequantises to +/-0.0 and contributes nothing to the running sum
         for (uint32_t k = 0; k < glc::kHop; ++k)
           if (dense[k] != INT32_MIN && dense[k] != 0)
-            pairs.push_back(k | (static_cast<uint32_t>(static_cast<uint16_t>(dense[k])) << 16));
+            extra.push_back(k | (static_cast<uint32_t>(static_cast<uint16_t>(dense[k])) << 16));
+        row_cnt[m] = static_cast<uint32_t>(n_stored + extra.size() - row_begin[m]);
       }
-      row_scale[f * ch + c] = in->scales[s0 + c];
-      row_off[f * ch + c + 1] = pairs.size();
+      row_scale[m] = in->scales[s0 + c];
     }
   }
 
   DeviceGuard guard(ctx->device);
-  // upload metadata
   size_t off = 0;
   auto place = [&](size_t bytes) {
     size_t at = off;
     off = align_up(off + bytes, 256);
     return at;
   };
-  const size_t o_pairs = place(std::max<size_t>(pairs.size(), 1) * 4);
-  const size_t o_off = place((M + 1) * 8);
+  const size_t o_pairs = place(std::max<size_t>(n_stored + extra.size(), 1) * 4);
+  const size_t o_begin = place(std::max<size_t>(M, 1) * 8);
+  const size_t o_cnt = place(std::max<size_t>(M, 1) * 4);
   const size_t o_scale = place(std::max<size_t>(M, 1) * 4);
   const size_t o_raw = place(std::max<size_t>(M, 1) * 8);
   const size_t o_rawlen = place(std::max<size_t>(M, 1) * 8);
   const size_t o_pool = place(std::max<size_t>(in->raw.size(), 1) * 2);
+  GLC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // a previous session may still read dec_meta
   GLC_HIP(ctx, ctx->dec_meta.reserve(off));
   uint8_t *mb = static_cast<uint8_t *>(ctx->dec_meta.p);
   auto up = [&](size_t o, const void *src, size_t bytes) -> hipError_t {
     if (!bytes) return hipSuccess;
     return hipMemcpyAsync(mb + o, src, bytes, hipMemcpyHostToDevice, ctx->stream);
   };
-  GLC_HIP(ctx, up(o_pairs, pairs.data(), pairs.size() * 4));
-  GLC_HIP(ctx, up(o_off, row_off.data(), (M + 1) * 8));
+  GLC_HIP(ctx, up(o_pairs, in->pairs.data(), n_stored * 4));
+  GLC_HIP(ctx, up(o_pairs + n_stored * 4, extra.data(), extra.size() * 4));
+  GLC_HIP(ctx, up(o_begin, row_begin.data(), M * 8));
+  GLC_HIP(ctx, up(o_cnt, row_cnt.data(), M * 4));
   GLC_HIP(ctx, up(o_scale, row_scale.data(), M * 4));
   GLC_HIP(ctx, up(o_raw, row_raw.data(), M * 8));
   GLC_HIP(ctx, up(o_rawlen, row_raw_len.data(), M * 8));
   GLC_HIP(ctx, up(o_pool, in->raw.data(), in->raw.size() * 2));
-  glc::DecodeRows rows{reinterpret_cast<const uint32_t *>(mb + o_pairs),
-                       reinterpret_cast<const uint64_t *>(mb + o_off),
-                       reinterpret_cast<const float *>(mb + o_scale),
-                       reinterpret_cast<const int64_t *>(mb + o_raw),
-                       reinterpret_cast<const uint64_t *>(mb + o_rawlen),
-                       reinterpret_cast<const int16_t *>(mb + o_pool)};
+  GLC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host vectors above go out of scope
+  ctx->dec_rows = glc::DecodeRows{reinterpret_cast<const uint32_t *>(mb + o_pairs),
+                                  reinterpret_cast<const uint64_t *>(mb + o_begin),
+                                  reinterpret_cast<const uint32_t *>(mb + o_cnt),
+                                  reinterpret_cast<const float *>(mb + o_scale),
+                                  reinterpret_cast<const int64_t *>(mb + o_raw),
+                                  reinterpret_cast<const uint64_t *>(mb + o_rawlen),
+                                  reinterpret_cast<const int16_t *>(mb + o_pool)};
+  ctx->dec_ch = ch;
+  ctx->dec_frames = nf;
+  ctx->dec_next = 0;
+  return GLC_OK;
+}
 
-  // Chunked: blocks buffer = slot 0 (frame before the chunk) + up to kDecodeChunkFrames frames.
-  const uint64_t total = (nf + 1) * glc::kHop * ch;
-  try {
-    all.resize(total);
-  } catch (const std::bad_alloc &) {
-    return fail(ctx, GLC_ENOMEM, "glc_decode: host allocation failed");
-  }
-  const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(kDecodeChunkFrames, nf));
+// Decode frames [dec_next, dec_next + n) and copy the part of their output that falls inside
+// [want_lo, want_hi) — indices into the un-trimmed interleaved stream of (nf+1)*1024*ch samples
+// that decode_streaming emits (src/codec.rs:688-732) — to dst (dst[0] <-> stream index want_lo).
+// emit_tail: also produce the hop after the last frame, the bare overlap tail (:722-729); only
+// valid when the chunk ends at the last frame.
+int decode_chunk(glc_ctx *ctx, uint64_t n, bool emit_tail, float *dst, uint64_t want_lo, uint64_t want_hi) {
+  const uint32_t ch = ctx->dec_ch;
+  const uint64_t nf = ctx->dec_frames, f0 = ctx->dec_next;
   const size_t slot = static_cast<size_t>(ch) * glc::kFrame;  // floats per frame
-  GLC_HIP(ctx, ctx->blocks.reserve((chunk + 1) * slot * sizeof(float)));
-  GLC_HIP(ctx, ctx->pcm.reserve((chunk + 1) * glc::kHop * ch * sizeof(float)));
+  DeviceGuard guard(ctx->device);
+  GLC_HIP(ctx, ctx->blocks.reserve((std::max<uint64_t>(n, 1) + 1) * slot * sizeof(float)));
+  GLC_HIP(ctx, ctx->pcm.reserve((std::max<uint64_t>(n, 1) + 1) * glc::kHop * ch * sizeof(float)));
   float *blocks = static_cast<float *>(ctx->blocks.p);
   float *dout = static_cast<float *>(ctx->pcm.p);
-  GLC_HIP(ctx, hipMemsetAsync(blocks, 0, slot * sizeof(float), ctx->stream));  // overlap = 0.0, :601
-  if (nf == 0) {
-    // no frames: the output is the 1024*ch zeros of the initial overlap, :722-729
-    std::fill(all.begin(), all.end(), 0.0f);
-    GLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return GLC_OK;
+  if (f0 == 0) {
+    // overlap = 0.0 (:601).  A grown workspace is also fresh, which is fine at frame 0 only:
+    GLC_HIP(ctx, hipMemsetAsync(blocks, 0, slot * sizeof(float), ctx->stream));
   }
-  for (uint64_t f0 = 0; f0 < nf; f0 += chunk) {
-    const uint64_t n = std::min(chunk, nf - f0);
-    GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, rows, static_cast<uint32_t>(f0 * ch),
+  if (f0 + n > nf || (emit_tail && f0 + n != nf)) return fail(ctx, GLC_EINVAL, "decode_chunk: bad range");
+  const uint64_t hop_end = f0 + n + (emit_tail ? 1 : 0);
+  if (n)
+    GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, static_cast<uint32_t>(f0 * ch),
                                         static_cast<uint32_t>(n * ch), ch, blocks + slot, ctx->stream));
-    const bool last = f0 + n == nf;
-    const uint64_t hop_end = f0 + n + (last ? 1 : 0);  // the final chunk also emits the tail hop
-    GLC_HIP(ctx, glc::launch_overlap_add(blocks, static_cast<int64_t>(f0) - 1, nf, ch, f0, hop_end,
-                                         dout, ctx->stream));
-    GLC_HIP(ctx, hipMemcpyAsync(all.data() + f0 * glc::kHop * ch, dout,
-                                (hop_end - f0) * glc::kHop * ch * sizeof(float), hipMemcpyDeviceToHost,
+  GLC_HIP(ctx, glc::launch_overlap_add(blocks, static_cast<int64_t>(f0) - 1, nf, ch, f0, hop_end, dout,
+                                       ctx->stream));
+  const uint64_t c_lo = f0 * glc::kHop * ch, c_hi = hop_end * glc::kHop * ch;
+  const uint64_t lo = std::max(c_lo, want_lo), hi = std::min(c_hi, want_hi);
+  if (hi > lo)
+    GLC_HIP(ctx, hipMemcpyAsync(dst + (lo - want_lo), dout + (lo - c_lo), (hi - lo) * sizeof(float),
+                                hipMemcpyDeviceToHost, ctx->stream));
+  if (!emit_tail && n)  // carry the chunk's last frame into slot 0 for the next chunk's overlap-add
+    GLC_HIP(ctx, hipMemcpyAsync(blocks, blocks + n * slot, slot * sizeof(float), hipMemcpyDeviceToDevice,
                                 ctx->stream));
-    if (!last)  // carry the chunk's last frame into slot 0
-      GLC_HIP(ctx, hipMemcpyAsync(blocks, blocks + n * slot, slot * sizeof(float),
-                                  hipMemcpyDeviceToDevice, ctx->stream));
-    GLC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `all` is pageable: keep the copy ordered
-  }
+  GLC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // dst is pageable: keep the copy ordered
+  ctx->dec_next = f0 + n;
   return GLC_OK;
 }
 
@@ -507,31 +627,43 @@ int decode_all(glc_ctx *ctx, const glc_frames *in, std::vector<float> &all) {
 
 int glc_decode(glc_ctx *ctx, const glc_frames *in, float *pcm_out, uint64_t cap, uint64_t *n_out) {
   if (!ctx || !in || (!pcm_out && cap)) return fail(ctx, GLC_EINVAL, "glc_decode: null argument");
-  const uint64_t want = glc_decoded_len(in);
-  if (n_out) *n_out = want;
-  if (cap < want) return fail(ctx, GLC_EINVAL, "glc_decode: output buffer too small");
-  std::vector<float> all;
-  int rc = decode_all(ctx, in, all);
-  if (rc != GLC_OK) return rc;
+  ctx->stream_open = false;
   // gapless trim, src/codec.rs:756-765 (delay counted in INTERLEAVED samples, quirk Q3)
-  uint64_t start = 0, n = all.size();
+  const uint64_t all = (in->n_frames + 1) * static_cast<uint64_t>(glc::kHop) * in->channels;
+  uint64_t start = 0, n = all;
   if (n > in->encoder_delay) {
     start = in->encoder_delay;
     n -= in->encoder_delay;
   }
   if (n > in->original_length) n = in->original_length;
-  if (n) std::memcpy(pcm_out, all.data() + start, n * sizeof(float));
   if (n_out) *n_out = n;
+  if (cap < n) return fail(ctx, GLC_EINVAL, "glc_decode: output buffer too small");
+  int rc = decode_prepare(ctx, in);
+  if (rc != GLC_OK) return rc;
+  // the blocks ring must not be re-allocated between chunks (slot 0 carries state): size it once
+  const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(kDecodeChunkFrames, in->n_frames));
+  {
+    DeviceGuard guard(ctx->device);
+    GLC_HIP(ctx, ctx->blocks.reserve((chunk + 1) * static_cast<size_t>(in->channels) * glc::kFrame * sizeof(float)));
+  }
+  do {
+    const uint64_t left = ctx->dec_frames - ctx->dec_next;
+    rc = decode_chunk(ctx, std::min(chunk, left), left <= chunk, pcm_out, start, start + n);
+    if (rc != GLC_OK) return rc;
+  } while (ctx->dec_next < ctx->dec_frames);
   return GLC_OK;
 }
 
 int glc_decode_stream_begin(glc_ctx *ctx, const glc_frames *in) {
   if (!ctx || !in) return fail(ctx, GLC_EINVAL, "glc_decode_stream_begin: null argument");
   ctx->stream_open = false;
-  int rc = decode_all(ctx, in, ctx->stream_pcm);
+  int rc = decode_prepare(ctx, in);
   if (rc != GLC_OK) return rc;
-  ctx->stream_pos = 0;
-  ctx->stream_ch = in->channels;
+  {
+    DeviceGuard guard(ctx->device);
+    GLC_HIP(ctx, ctx->blocks.reserve((static_cast<size_t>(GLC_FRAMES_PER_CHUNK) + 1) * in->channels * glc::kFrame *
+                                     sizeof(float)));
+  }
   ctx->stream_open = true;
   return GLC_OK;
 }
@@ -539,29 +671,20 @@ int glc_decode_stream_begin(glc_ctx *ctx, const glc_frames *in) {
 int glc_decode_stream_next(glc_ctx *ctx, float *chunk, uint64_t cap, uint64_t *n_out, int *is_last) {
   if (!ctx || !n_out || !is_last) return fail(ctx, GLC_EINVAL, "glc_decode_stream_next: null argument");
   if (!ctx->stream_open) return fail(ctx, GLC_EINVAL, "glc_decode_stream_next: no stream open");
-  // src/codec.rs:708-717: a chunk is flushed once it holds >= 500 frames; the remainder plus the
-  // overlap tail forms the last chunk (:722-732).
-  const uint64_t per_chunk = static_cast<uint64_t>(GLC_FRAMES_PER_CHUNK) * glc::kHop * ctx->stream_ch;
-  const uint64_t total = ctx->stream_pcm.size();
-  const uint64_t body = total - static_cast<uint64_t>(glc::kHop) * ctx->stream_ch;  // frames' hops
-  uint64_t n;
-  bool last;
-  if (body - ctx->stream_pos >= per_chunk && ctx->stream_pos < body) {
-    n = per_chunk;
-    last = false;
-  } else {
-    n = total - ctx->stream_pos;
-    last = true;
-  }
+  // src/codec.rs:708-717: a chunk is flushed once it holds >= 500 frames; the remaining frames
+  // plus the overlap tail form the last chunk (:722-732).  Each call decodes only its own frames.
+  const uint64_t left = ctx->dec_frames - ctx->dec_next;
+  const bool last = left < GLC_FRAMES_PER_CHUNK;
+  const uint64_t frames = last ? left : GLC_FRAMES_PER_CHUNK;
+  const uint64_t per_hop = static_cast<uint64_t>(glc::kHop) * ctx->dec_ch;
+  const uint64_t n = (frames + (last ? 1 : 0)) * per_hop;
   *n_out = n;
   *is_last = last ? 1 : 0;
   if (cap < n || (!chunk && n)) return fail(ctx, GLC_EINVAL, "glc_decode_stream_next: chunk buffer too small");
-  if (n) std::memcpy(chunk, ctx->stream_pcm.data() + ctx->stream_pos, n * sizeof(float));
-  ctx->stream_pos += n;
-  if (last) {
-    ctx->stream_open = false;
-    std::vector<float>().swap(ctx->stream_pcm);
-  }
+  const uint64_t lo = ctx->dec_next * per_hop;
+  int rc = decode_chunk(ctx, frames, last, chunk, lo, lo + n);
+  if (rc != GLC_OK) return rc;
+  if (last) ctx->stream_open = false;
   return GLC_OK;
 }
 

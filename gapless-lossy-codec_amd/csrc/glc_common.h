@@ -72,4 +72,7 @@ struct glc_frames {
   std::vector<uint32_t> pairs;     // (u16 idx) | (u16 q << 16), stream order
   std::vector<float> scales;
   std::vector<int16_t> raw;
+  // true when every sparse list is known to be strictly ascending with idx < 1024 (streams
+  // assembled from this library's own records); streams read from bytes are checked at decode
+  bool lists_canonical = false;
 };

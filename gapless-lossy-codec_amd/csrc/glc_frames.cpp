@@ -159,6 +159,7 @@ int glc_frames_from_records(uint32_t sample_rate, uint64_t n_samples, uint16_t c
   } catch (const std::bad_alloc &) {
     return GLC_ENOMEM;
   }
+  F->lists_canonical = true;  // built by an ascending scan of dense rows
   *out = F.release();
   return GLC_OK;
 }

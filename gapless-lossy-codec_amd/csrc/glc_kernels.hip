@@ -249,8 +249,8 @@ __global__ __launch_bounds__(256) void k_imdct_rows(DeviceTables tb, DecodeRows 
     return;
   }
 
-  const unsigned long long p0 = rows.row_off[m], p1 = rows.row_off[m + 1];
-  const unsigned n = static_cast<unsigned>(p1 - p0);
+  const unsigned long long p0 = rows.row_begin[m];
+  const unsigned n = min(rows.row_cnt[m], static_cast<unsigned>(kHopI));  // canonical lists hold <= 1024
   const float scale = fmaxf(rows.row_scale[m], 1e-12f);  // :653
   for (unsigned j = tid; j < n; j += 256) {
     const unsigned pr = rows.pairs[p0 + j];
@@ -315,6 +315,120 @@ __global__ __launch_bounds__(256) void k_overlap_add(const float *__restrict__ b
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// P1-P3: device-side compaction of frame records into the bitstream's sparse form, so that the
+// host boundary (and a gather) moves (u16 idx, i16 q) pairs instead of dense 1024-bin rows.
+//   P1  per row: pairs it contributes (nnz, 0 for rows of raw frames); exclusive scan inside
+//       blocks of 1024 rows; compact per-row scale and per-frame raw flag
+//   P2  exclusive scan of the block totals (one workgroup)
+//   P3  one wave per row: ballot + popcount prefix keeps ascending k (src/codec.rs:303-306)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_scan_rows(const unsigned char *__restrict__ records, unsigned M,
+                                                         unsigned ch, unsigned long long rec_bytes,
+                                                         unsigned *__restrict__ loc,
+                                                         unsigned long long *__restrict__ blk,
+                                                         unsigned long long *__restrict__ blk_raw,
+                                                         float *__restrict__ scales,
+                                                         unsigned char *__restrict__ is_raw) {
+  // one 32-bit word scans both counts: low 21 bits = pairs (<= 1024*1024 per block), high 11 =
+  // rows of raw frames (<= 1024 per block)
+  __shared__ unsigned s_part[256];
+  const unsigned base = blockIdx.x * 1024u + threadIdx.x * 4u;
+  unsigned v[4], sum = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned m = base + j;
+    unsigned n = 0;
+    if (m < M) {
+      const unsigned frame = m / ch, c = m % ch;
+      const unsigned char *rec = records + static_cast<size_t>(frame) * rec_bytes;
+      const unsigned raw = *reinterpret_cast<const unsigned *>(rec);
+      n = raw ? (1u << 21) : *reinterpret_cast<const unsigned *>(rec + 8 + 8 * c + 4);
+      scales[m] = *reinterpret_cast<const float *>(rec + 8 + 8 * c);
+      if (c == 0) is_raw[frame] = raw ? 1 : 0;
+    }
+    v[j] = sum;  // exclusive within the thread
+    sum += n;
+  }
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan of the 256 thread sums
+    unsigned t = threadIdx.x >= static_cast<unsigned>(off) ? s_part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    s_part[threadIdx.x] += t;
+    __syncthreads();
+  }
+  const unsigned before = threadIdx.x ? s_part[threadIdx.x - 1] : 0u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (base + j < M) loc[base + j] = before + v[j];
+  if (threadIdx.x == 255) {
+    blk[blockIdx.x] = s_part[255] & 0x1FFFFFu;
+    blk_raw[blockIdx.x] = s_part[255] >> 21;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_pack_scan_blocks(unsigned long long *__restrict__ blk, unsigned n,
+                                                            unsigned long long *__restrict__ total) {
+  __shared__ unsigned long long s[1024];
+  unsigned long long carry = 0;
+  for (unsigned b0 = 0; b0 < n; b0 += 1024) {
+    const unsigned i = b0 + threadIdx.x;
+    const unsigned long long mine = i < n ? blk[i] : 0ull;
+    s[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      unsigned long long t = threadIdx.x >= static_cast<unsigned>(off) ? s[threadIdx.x - off] : 0ull;
+      __syncthreads();
+      s[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < n) blk[i] = carry + s[threadIdx.x] - mine;  // exclusive
+    const unsigned long long chunk_total = s[1023];
+    __syncthreads();
+    carry += chunk_total;
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void k_pack_rows(const unsigned char *__restrict__ records, unsigned M,
+                                                    unsigned ch, unsigned long long rec_bytes,
+                                                    unsigned long long hdr_bytes, const unsigned *__restrict__ loc,
+                                                    const unsigned long long *__restrict__ blk,
+                                                    const unsigned long long *__restrict__ blk_raw,
+                                                    unsigned *__restrict__ pairs,
+                                                    unsigned long long *__restrict__ row_off,
+                                                    short *__restrict__ raw_pool) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const unsigned m = blockIdx.x * 4 + w;
+  if (m >= M) return;
+  const unsigned l = loc[m];
+  const unsigned long long off = blk[m >> 10] + (l & 0x1FFFFFu);
+  if (lane == 0) row_off[m] = off;
+  const unsigned frame = m / ch, c = m % ch;
+  const unsigned char *rec = records + static_cast<size_t>(frame) * rec_bytes;
+  const short *qrow = reinterpret_cast<const short *>(rec + hdr_bytes) + static_cast<size_t>(c) * kFrameI;
+  if (*reinterpret_cast<const unsigned *>(rec)) {
+    // row of a raw frame: its 2048-sample plane goes to the raw pool (planar order == row order, Q1)
+    const unsigned long long rrow = blk_raw[m >> 10] + (l >> 21);
+    const short4 *src = reinterpret_cast<const short4 *>(qrow);
+    short4 *dst = reinterpret_cast<short4 *>(raw_pool + rrow * kFrameI);
+    for (int i = lane; i < kFrameI / 4; i += 64) dst[i] = src[i];
+    return;
+  }
+  unsigned *dst = pairs + off;
+  unsigned done = 0;
+  for (int k0 = 0; k0 < kHopI; k0 += 64) {
+    const short q = qrow[k0 + lane];
+    const unsigned long long mask = __ballot(q != 0);
+    if (q != 0) {
+      const unsigned pos = done + __popcll(mask & ((1ull << lane) - 1ull));
+      dst[pos] = static_cast<unsigned>(k0 + lane) | (static_cast<unsigned>(static_cast<unsigned short>(q)) << 16);
+    }
+    done += __popcll(mask);
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------- launchers
@@ -346,6 +460,34 @@ hipError_t launch_decide_raw(const DeviceTables &t, const PcmView &pcm, uint64_t
   const unsigned long long rec = hdr + 2ull * kFrameI * pcm.ch;
   hipLaunchKernelGGL(k_decide_raw, dim3(n_frames), dim3(256), 0, s, t, pcm,
                      static_cast<long long>(frame_begin), n_frames, rec, hdr, records);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_scan(const uint8_t *records, uint32_t M, uint32_t ch, uint32_t *loc, uint64_t *blk,
+                            uint64_t *blk_raw, uint64_t *totals, float *scales, uint8_t *is_raw, hipStream_t s) {
+  if (M == 0) return hipMemsetAsync(totals, 0, 2 * sizeof(uint64_t), s);
+  const unsigned long long hdr = ((8ull + 8ull * ch) + 15ull) & ~15ull;
+  const unsigned long long rec = hdr + 2ull * kFrameI * ch;
+  const unsigned nblk = (M + 1023) / 1024;
+  auto *b = reinterpret_cast<unsigned long long *>(blk);
+  auto *br = reinterpret_cast<unsigned long long *>(blk_raw);
+  auto *t = reinterpret_cast<unsigned long long *>(totals);
+  hipLaunchKernelGGL(k_pack_scan_rows, dim3(nblk), dim3(256), 0, s, records, M, ch, rec, loc, b, br, scales, is_raw);
+  hipLaunchKernelGGL(k_pack_scan_blocks, dim3(1), dim3(1024), 0, s, b, nblk, t);
+  hipLaunchKernelGGL(k_pack_scan_blocks, dim3(1), dim3(1024), 0, s, br, nblk, t + 1);
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_rows(const uint8_t *records, uint32_t M, uint32_t ch, const uint32_t *loc,
+                            const uint64_t *blk, const uint64_t *blk_raw, uint32_t *pairs, uint64_t *row_off,
+                            int16_t *raw_pool, hipStream_t s) {
+  if (M == 0) return hipSuccess;
+  const unsigned long long hdr = ((8ull + 8ull * ch) + 15ull) & ~15ull;
+  const unsigned long long rec = hdr + 2ull * kFrameI * ch;
+  hipLaunchKernelGGL(k_pack_rows, dim3((M + 3) / 4), dim3(256), 0, s, records, M, ch, rec, hdr, loc,
+                     reinterpret_cast<const unsigned long long *>(blk),
+                     reinterpret_cast<const unsigned long long *>(blk_raw), pairs,
+                     reinterpret_cast<unsigned long long *>(row_off), raw_pool);
   return hipGetLastError();
 }
 

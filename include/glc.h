@@ -136,6 +136,13 @@ int glc_mdct_forward_device(glc_ctx *ctx, const float *d_pcm, uint64_t t0, uint6
 int glc_frames_from_records(uint32_t sample_rate, uint64_t n_samples, uint16_t channels,
                             const void *records, uint64_t n_frames, glc_frames **out);
 
+/* Same result as glc_frames_from_records, from records still on the device (this context's
+ * device; e.g. right after glc_encode_range_device, or on the gather root): the sparse lists are
+ * compacted on the device (scan + ballot pack, ascending k) and only the bitstream's payload —
+ * (u16, i16) pairs, scale factors, raw planes of raw frames — crosses to the host.  Synchronises. */
+int glc_frames_from_device_records(glc_ctx *ctx, const void *d_records, uint64_t n_frames,
+                                   uint64_t n_samples, uint16_t channels, glc_frames **out);
+
 /* ---- decode --------------------------------------------------------------------------- */
 
 /* Length Decoder::decode will return: min(original_length, (n_frames+1)*1024*ch - delay). */

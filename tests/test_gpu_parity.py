@@ -356,3 +356,44 @@ def test_cfg5_eight_channel_192k(torch_cuda):
     assert dec.size == x.size
     dref, _, _ = O.decode(ref.glc)
     assert np.array_equal(bits(dec[:30 * 1024 * ch]), bits(dref[:30 * 1024 * ch]))
+
+
+def test_device_side_compaction_equals_host_assembly(torch_cuda):
+    """glc_frames_from_device_records (scan + ballot pack on the GPU) == glc_frames_from_records
+    (host scan of the dense rows), on a stream mixing compressed and raw frames."""
+    sr, ch = 44100, 3
+    x = np.concatenate([gen_chord(sr, ch, 9000), gen_noise(sr, ch, 0.2, 5), gen_chord(sr, ch, 3000, seed=2),
+                        gen_noise(sr, ch, 0.05, 6)])
+    plan = glc_amd.plan_encode(x.size, ch)
+    rec = glc_amd.lib.glc_record_bytes(ch)
+    d_pcm = torch_cuda.from_numpy(x).cuda()
+    d_rec = torch_cuda.zeros(plan.n_frames * rec, dtype=torch_cuda.uint8, device="cuda")
+    enc = glc_amd.Encoder(sr)
+    torch_cuda.cuda.synchronize()
+    enc.encode_range_device(d_pcm.data_ptr(), 0, x.size // ch, x.size, ch, 0, plan.n_frames, d_rec.data_ptr())
+    enc.synchronize()
+    a = enc.frames_from_device_records(d_rec.data_ptr(), plan.n_frames, x.size, ch)
+    b = glc_amd.EncodedAudio.from_records(sr, x.size, ch, d_rec.cpu().numpy())
+    assert 0 < a.info().n_raw_frames < plan.n_frames
+    assert a.to_bytes() == b.to_bytes() == O.encode(x, sr, ch).glc
+
+
+@pytest.mark.parametrize("n_frames", [499, 500, 501, 1000, 1203])
+def test_streaming_chunk_boundaries(torch_cuda, n_frames):
+    """decode_streaming chunking (src/codec.rs:708-732): a chunk per 500 frames, the remainder plus
+    the overlap tail in the last chunk; each chunk decoded on demand, all bits equal to decode()."""
+    sr, ch = 48000, 2
+    x = gen_chord(sr, ch, n_frames * 1024, n_tones=4)
+    assert glc_amd.plan_encode(x.size, ch).n_frames == n_frames
+    enc = glc_amd.Encoder(sr).encode(x, ch)
+    dec = glc_amd.Decoder(ch, sr)
+    whole = dec.decode(enc)
+    chunks = list(dec.decode_streaming(enc))
+    sizes = [c.samples.size // (1024 * ch) for c in chunks]
+    full, rem = divmod(n_frames, 500)
+    assert sizes == [500] * full + [rem + 1]
+    assert [c.is_last for c in chunks] == [False] * full + [True]
+    allv = np.concatenate([c.samples for c in chunks])
+    assert np.array_equal(bits(allv[512:512 + whole.size]), bits(whole))
+    # a second decode on the same Decoder (fresh session) gives the same bits
+    assert np.array_equal(bits(dec.decode(enc)), bits(whole))
