@@ -399,14 +399,18 @@ __device__ __forceinline__ void mac_step(f32x2 (&acc)[TM][4], const Operands &o)
 // SCALAR = v_mul_f32/v_add_f32 stream (TM == 4 only) instead of the packed v_pk_* one: on
 // gfx950 both forms have the same peak MAC rate, but the 2-cycle scalar ops reach it with fewer
 // waves per SIMD (profiles/r01_microbench_valu_mfma.txt: A vs B).
-template <int BM, int BN, int BK, int MINW, int ABL = 0, int TM = 8, bool SCALAR = false>
+// RING = LDS slots per operand tile: 2 = classic double buffer (stage s+1 is written at the end
+// of stage s, so its ds_writes must land before the barrier); 3 = stage s+2 is written at the end
+// of stage s into the slot nobody reads, the barrier publishes the writes of the PREVIOUS stage
+// and needs no LDS wait in front of it.
+template <int BM, int BN, int BK, int MINW, int ABL = 0, int TM = 8, bool SCALAR = false, int RING = 2>
 __global__ __launch_bounds__((BM / TM) * (BN / 8)) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
 void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm, long long frame_begin, unsigned M,
                       float *__restrict__ coef) {
   using C = Cfg<BM, BN, BK, TM, 8, 2, MINW>;
   static_assert(!SCALAR || TM == 4, "scalar stream is written for the 4x8 lane tile");
-  __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+  __shared__ __attribute__((aligned(16))) float As[RING][BK * BM];
+  __shared__ __attribute__((aligned(16))) float Bs[RING][BK * BN];
 
   const int tid = threadIdx.x;
   // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 says which blocks share an
@@ -504,6 +508,10 @@ void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm, long long frame_begin, unsig
 
   load_stage(0);
   store_stage(0);
+  if (RING == 3) {
+    load_stage(BK);
+    store_stage(1);
+  }
   __syncthreads();
 
   // LDS byte addresses of this lane's operand columns (low 32 bits of a generic LDS pointer)
@@ -513,8 +521,8 @@ void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm, long long frame_begin, unsig
   constexpr int kStages = kFrameI / BK;
 #pragma unroll 1
   for (int s = 0; s < kStages; ++s) {
-    const int buf = s & 1;
-    if (ABL == 0) load_stage(((s + 1) & (kStages - 1)) * BK);
+    const int buf = RING == 3 ? s % 3 : (s & 1);
+    if (ABL == 0) load_stage(((s + RING - 1) & (kStages - 1)) * BK);
     const unsigned a_addr = a_lds0 + buf * (BK * BM * 4);
     const unsigned b_addr = b_lds0 + buf * (BK * BN * 4);
     Operands X, Y;
@@ -550,8 +558,13 @@ void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm, long long frame_begin, unsig
       }
     }
     if (ABL == 0) {
-      store_stage(buf ^ 1);
-      __syncthreads();
+      if (RING == 3) {
+        store_stage((s + 2) % 3);
+        __builtin_amdgcn_s_barrier();  // publishes the writes made one stage ago; no LDS wait
+      } else {
+        store_stage(buf ^ 1);
+        __syncthreads();
+      }
     }
   }
 
@@ -574,13 +587,13 @@ void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm, long long frame_begin, unsig
   }
 }
 
-template <int BM, int BN, int BK, int MINW, int ABL = 0, int TM = 8, bool SCALAR = false>
+template <int BM, int BN, int BK, int MINW, int ABL = 0, int TM = 8, bool SCALAR = false, int RING = 2>
 inline hipError_t launch_sched(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M,
                                float *coef, hipStream_t s) {
   using C = Cfg<BM, BN, BK, TM, 8, 2, MINW>;
   if (M == 0) return hipSuccess;
   const unsigned m_tiles = (M + BM - 1) / BM;
-  hipLaunchKernelGGL((k_mdct_fwd_sched<BM, BN, BK, MINW, ABL, TM, SCALAR>), dim3(m_tiles * C::kNTiles),
+  hipLaunchKernelGGL((k_mdct_fwd_sched<BM, BN, BK, MINW, ABL, TM, SCALAR, RING>), dim3(m_tiles * C::kNTiles),
                      dim3(C::kThreads), 0, s, t, pcm,
                      static_cast<long long>(frame_begin), M, coef);
   return hipGetLastError();
