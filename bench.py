@@ -77,8 +77,11 @@ def main():
     # GLC_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks
     # then share devices and the gather goes through host memory); the real run uses nccl = RCCL.
     backend = os.environ.get("GLC_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank = local_rank % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    if backend != "nccl" or ndev <= local_rank:
+        # rehearsal on fewer GPUs than ranks, or a launcher that exposes one device per rank
+        # (HIP_VISIBLE_DEVICES): index within what this process can see
+        local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
