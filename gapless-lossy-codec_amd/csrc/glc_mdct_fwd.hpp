@@ -395,7 +395,8 @@ __device__ __forceinline__ void mac_step(f32x2 (&acc)[TM][4], const Operands &o)
 }
 
 // ABL (tuning only, results are wrong when != 0): 1 = no staging/barrier inside the stage loop,
-// 2 = additionally no LDS operand reads inside the loop (pure VALU stream).
+// 2 = additionally no LDS operand reads inside the loop (pure VALU stream), 3 = staging but no
+// barrier, 4 = barrier but no staging.
 // SCALAR = v_mul_f32/v_add_f32 stream (TM == 4 only) instead of the packed v_pk_* one: on
 // gfx950 both forms have the same peak MAC rate, but the 2-cycle scalar ops reach it with fewer
 // waves per SIMD (profiles/r01_microbench_valu_mfma.txt: A vs B).
@@ -522,7 +523,7 @@ void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm, long long frame_begin, unsig
 #pragma unroll 1
   for (int s = 0; s < kStages; ++s) {
     const int buf = RING == 3 ? s % 3 : (s & 1);
-    if (ABL == 0) load_stage(((s + RING - 1) & (kStages - 1)) * BK);
+    if (ABL == 0 || ABL == 3) load_stage(((s + RING - 1) & (kStages - 1)) * BK);
     const unsigned a_addr = a_lds0 + buf * (BK * BM * 4);
     const unsigned b_addr = b_lds0 + buf * (BK * BN * 4);
     Operands X, Y;
@@ -557,6 +558,8 @@ void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm, long long frame_begin, unsig
         if (ABL != 2 && ii + 2 < BK) wait(X);
       }
     }
+    if (ABL == 3) store_stage(buf ^ 1);
+    if (ABL == 4) __syncthreads();
     if (ABL == 0) {
       if (RING == 3) {
         store_stage((s + 2) % 3);

@@ -95,16 +95,15 @@ int main(int argc, char **argv) {
 
   // hand-scheduled kernels (shipped shapes first), their ablations, then hipcc-scheduled shapes
   std::vector<Variant> vs = {
-      Variant{"sched pk  64x128 bk16 t4x8 w4 (shipped, M < 16384)", k1::launch_sched<64, 128, 16, 4, 0, 4>},
-      Variant{"sched pk 128x128 bk16 t8x8 w3 (shipped, M >= 16384)", k1::launch_sched<128, 128, 16, 3, 0, 8>},
+      Variant{"sched pk 128x128 bk16 t4x8 w4 512thr (shipped, M < 16384)", k1::launch_sched<128, 128, 16, 4, 0, 4>},
+      Variant{"sched pk 128x128 bk16 t8x8 w3 256thr (shipped, M >= 16384)", k1::launch_sched<128, 128, 16, 3, 0, 8>},
+      Variant{"  512thr ABL1 (no staging, no barrier)", k1::launch_sched<128, 128, 16, 4, 1, 4>},
+      Variant{"  512thr ABL2 (pure VALU stream)", k1::launch_sched<128, 128, 16, 4, 2, 4>},
+      Variant{"  512thr ABL3 (staging, no barrier)", k1::launch_sched<128, 128, 16, 4, 3, 4>},
+      Variant{"  512thr ABL4 (barrier, no staging)", k1::launch_sched<128, 128, 16, 4, 4, 4>},
+      Variant{"sched pk  64x128 bk16 t4x8 w4 256thr", k1::launch_sched<64, 128, 16, 4, 0, 4>},
       Variant{"sched pk  64x128 bk16 t4x8 w4 ring3", k1::launch_sched<64, 128, 16, 4, 0, 4, false, 3>},
-      Variant{"sched pk  64x128 bk8  t4x8 w4 ring3", k1::launch_sched<64, 128, 8, 4, 0, 4, false, 3>},
-      Variant{"sched pk  64x128 bk32 t4x8 w4 ring3", k1::launch_sched<64, 128, 32, 4, 0, 4, false, 3>},
-      Variant{"sched pk 128x128 bk16 t8x8 w3 ring3", k1::launch_sched<128, 128, 16, 3, 0, 8, false, 3>},
-      Variant{"sched pk  64x128 ABL1 (no staging/barrier)", k1::launch_sched<64, 128, 16, 4, 1, 4>},
-      Variant{"sched pk  64x128 ABL2 (pure VALU stream)", k1::launch_sched<64, 128, 16, 4, 2, 4>},
       Variant{"sched sc  64x128 bk16 t4x8 w4 (scalar v_mul/v_add)", k1::launch_sched<64, 128, 16, 4, 0, 4, true>},
-      Variant{"sched pk 128x128 bk16 t4x8 w4 (512 threads)", k1::launch_sched<128, 128, 16, 4, 0, 4>},
       Variant{"sched pk  64x128 bk8  t4x8 w4", k1::launch_sched<64, 128, 8, 4, 0, 4>},
       Variant{"sched pk  64x128 bk32 t4x8 w4", k1::launch_sched<64, 128, 32, 4, 0, 4>},
       V(128, 128, 16, 8, 8, 2, 2), V(128, 128, 8, 8, 8, 2, 2), V(64, 128, 16, 4, 8, 2, 4),
