@@ -602,6 +602,160 @@ inline hipError_t launch_sched(const DeviceTables &t, const PcmView &pcm, uint64
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// LDS-DMA variant (128x128 tile, 512 threads, 4x8 outputs per lane, 3-slot LDS ring).
+// The table tile of stage s+2 is copied global -> LDS by `global_load_lds_dwordx4` while stages s
+// and s+1 compute: two stages of latency budget, no VGPRs and no ds_write for the table.  The PCM
+// tile (needs the window multiply) goes through registers one stage ahead, the window itself sits
+// in LDS.  All vector-memory operations of the loop are inline asm so that ONE counted
+// `s_waitcnt vmcnt(1)` per stage waits for the PCM loads and the table DMA of the NEXT stage while
+// leaving the DMA of the stage after it in flight.  Same arithmetic, same order.
+// ------------------------------------------------------------------------------------------
+template <int MINW, int ABL = 0>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
+void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigned M, float *__restrict__ coef) {
+  constexpr int BM = 128, BN = 128, BK = 16, TM = 4, RING = 3;
+  constexpr int kAPer = 4, kAStride = 4;
+  __shared__ __attribute__((aligned(16))) float As[RING][BK * BM];
+  __shared__ __attribute__((aligned(16))) float Bs[RING][BK * BN];
+  __shared__ __attribute__((aligned(16))) float Ws[kFrameI];
+
+  const int tid = threadIdx.x;
+  const unsigned g = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD-aware tile map
+  const int n_tile = g % 8;
+  const int m_tile = g / 8;
+  const int m0 = m_tile * BM;
+  const int n0 = n_tile * BN;
+  const int tx = tid % 16, ty = tid / 16;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+
+  for (int i = tid; i < kFrameI; i += 512) Ws[i] = tb.window[i];
+
+  const long long ch = pcm.ch;
+  const long long f0 = frame_begin + m0 / pcm.ch;
+  const long long e_first = (f0 * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * ch;
+  long long e_end = static_cast<long long>(pcm.t_count) * ch;
+  const long long n_rel = static_cast<long long>(pcm.n_samples) - static_cast<long long>(pcm.t0) * ch;
+  if (e_end > n_rel) e_end = n_rel;
+  const long long e_base = e_first < 0 ? 0 : e_first;
+  long long e_cnt = e_end - e_base;
+  if (e_cnt < 0) e_cnt = 0;
+  if (e_cnt > (1ll << 28)) e_cnt = 1ll << 28;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(pcm.p + e_base), 0, static_cast<int>(e_cnt * 4), 0x00020000);
+
+  const int a_r = tid % BM;
+  const int a_i = tid / BM;  // 0..3: i = a_i + 4 j
+  const unsigned a_row = m0 + a_r;
+  unsigned a_off = 0x80000000u;
+  if (a_row < M) {
+    const long long f = frame_begin + a_row / pcm.ch;
+    const long long c = a_row % pcm.ch;
+    const long long e_row = (f * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * ch + c;
+    a_off = static_cast<unsigned>((e_row - e_base + a_i * ch) * 4);
+  }
+  const unsigned a_step = static_cast<unsigned>(kAStride * ch * 4);
+  const unsigned i_bytes = static_cast<unsigned>(ch * 4);
+  // table DMA: wave w copies rows 2w, 2w+1 of the stage's 16 x 128 tile (1 KiB, lane-linear)
+  const float *b_src = tb.cos_t + n0 + static_cast<size_t>(2 * wave + (lane >> 5)) * kHopI + (lane & 31) * 4;
+
+  float a_raw[kAPer];
+  auto issue_a = [&](int i0) {  // asm: hipcc must not count these loads (see lds_fetch)
+    const unsigned o = a_off + static_cast<unsigned>(i0) * i_bytes;
+    asm volatile(
+        "buffer_load_dword %0, %4, %8, 0 offen\n\t"
+        "buffer_load_dword %1, %5, %8, 0 offen\n\t"
+        "buffer_load_dword %2, %6, %8, 0 offen\n\t"
+        "buffer_load_dword %3, %7, %8, 0 offen"
+        : "=&v"(a_raw[0]), "=&v"(a_raw[1]), "=&v"(a_raw[2]), "=&v"(a_raw[3])
+        : "v"(o), "v"(o + a_step), "v"(o + 2 * a_step), "v"(o + 3 * a_step), "s"(a_rsrc)
+        : "memory");
+  };
+  auto issue_b = [&](int i0, int slot) {
+    __builtin_amdgcn_global_load_lds(b_src + static_cast<size_t>(i0) * kHopI, &Bs[slot][2 * wave * BN], 16, 0, 0);
+  };
+  auto store_a = [&](int i0, int slot) {
+#pragma unroll
+    for (int j = 0; j < kAPer; ++j) {
+      const int ii = a_i + kAStride * j;
+      As[slot][ii * BM + a_r] = mul_rn(a_raw[j], Ws[i0 + ii]);  // block[i] = slice[i]*window[i], :480
+    }
+  };
+
+  f32x2 acc[TM][4];
+#pragma unroll
+  for (int r = 0; r < TM; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = f32x2{0.0f, 0.0f};
+
+  constexpr int kStages = kFrameI / BK;
+  // prologue: stage 0 complete in slot 0, table of stage 1 in flight to slot 1, PCM of stage 1 in regs
+  __syncthreads();  // Ws
+  issue_a(0);
+  issue_b(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a_raw[0]), "+v"(a_raw[1]), "+v"(a_raw[2]), "+v"(a_raw[3])::"memory");
+  store_a(0, 0);
+  issue_a(BK);
+  issue_b(BK, 1);
+  __syncthreads();
+
+  const unsigned a_lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(&As[0][ty * 4]));
+  const unsigned b_lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(&Bs[0][tx * 4]));
+
+#pragma unroll 1
+  for (int s = 0; s < kStages; ++s) {
+    const int slot = s % 3;
+    // in flight on entry: PCM loads of stage s+1 (regs) and table DMA of stage s+1 (slot (s+1)%3)
+    if (ABL == 0) issue_b(((s + 2) & (kStages - 1)) * BK, (s + 2) % 3);  // slot of stage s-1: free since the barrier
+    const unsigned a_addr = a_lds0 + slot * (BK * BM * 4);
+    const unsigned b_addr = b_lds0 + slot * (BK * BN * 4);
+    Operands X, Y;
+    lds_fetch4<BM, BN>(X, a_addr, b_addr, 0);
+    lds_wait4(X);
+#pragma unroll
+    for (int ii = 0; ii < BK; ii += 2) {
+      step4<BM, BN, true>(acc, X, Y, a_addr, b_addr, ii + 1);
+      if (ii + 2 < BK) step4<BM, BN, true>(acc, Y, X, a_addr, b_addr, ii + 2);
+      else step4<BM, BN, false>(acc, Y, X, a_addr, b_addr, 0);
+    }
+    if (ABL == 0) {
+      // everything but the youngest vector-memory op (the DMA of stage s+2) has landed: the PCM
+      // registers of stage s+1 and, older still, the table DMA of stage s+1
+      asm volatile("s_waitcnt vmcnt(1)" : "+v"(a_raw[0]), "+v"(a_raw[1]), "+v"(a_raw[2]), "+v"(a_raw[3])::"memory");
+      store_a(((s + 1) & (kStages - 1)) * BK, (s + 1) % 3);
+      issue_a(((s + 2) & (kStages - 1)) * BK);
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's ds_writes of stage s+1 have landed
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the wrap-around prefetches
+
+#pragma unroll
+  for (int r = 0; r < TM; ++r) {
+    const unsigned row = m0 + ty * 4 + r;
+    if (row >= M) continue;
+    float *dst = coef + static_cast<size_t>(row) * kHopI + n0;
+    float4 o;
+    o.x = mul_rn(acc[r][0].x, tb.norm); o.y = mul_rn(acc[r][0].y, tb.norm);
+    o.z = mul_rn(acc[r][1].x, tb.norm); o.w = mul_rn(acc[r][1].y, tb.norm);
+    *reinterpret_cast<float4 *>(dst + tx * 4) = o;
+    o.x = mul_rn(acc[r][2].x, tb.norm); o.y = mul_rn(acc[r][2].y, tb.norm);
+    o.z = mul_rn(acc[r][3].x, tb.norm); o.w = mul_rn(acc[r][3].y, tb.norm);
+    *reinterpret_cast<float4 *>(dst + BN / 2 + tx * 4) = o;
+  }
+}
+
+template <int MINW, int ABL = 0>
+inline hipError_t launch_dma(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M,
+                             float *coef, hipStream_t s) {
+  if (M == 0) return hipSuccess;
+  const unsigned m_tiles = (M + 127) / 128;
+  hipLaunchKernelGGL((k_mdct_fwd_dma<MINW, ABL>), dim3(m_tiles * 8), dim3(512), 0, s, t, pcm,
+                     static_cast<long long>(frame_begin), M, coef);
+  return hipGetLastError();
+}
+
 template <int BM, int BN, int BK, int TM, int TN, int UNROLL, int MINW>
 inline hipError_t launch(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M,
                          float *coef, hipStream_t s) {
