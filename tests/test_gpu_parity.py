@@ -397,3 +397,28 @@ def test_streaming_chunk_boundaries(torch_cuda, n_frames):
     assert np.array_equal(bits(allv[512:512 + whole.size]), bits(whole))
     # a second decode on the same Decoder (fresh session) gives the same bits
     assert np.array_equal(bits(dec.decode(enc)), bits(whole))
+
+
+def test_decode_degenerate_streams(torch_cuda):
+    """Streams no encoder emits but the container allows: zero frames; more channel vectors than
+    header.channels (extra ones ignored, src/codec.rs:648-653); original_length / delay larger than
+    the decoded stream."""
+    import struct
+    for sr, ch, frames, delay, orig in [(48000, 2, [], 512, 10), (44100, 1, [], 5000, 7),
+                                        (44100, 1, [[[(3, 1000)], [(9, -7)]]], 0, 10 ** 9)]:
+        body = b""
+        for lists in frames:
+            body += struct.pack("<Q", len(lists))
+            for l in lists:
+                body += struct.pack("<Q", len(l)) + b"".join(struct.pack("<Hh", i, q) for i, q in l)
+            body += struct.pack("<Q", len(lists)) + b"".join(struct.pack("<f", 0.5) for _ in lists) + b"\x00"
+        data = struct.pack("<IHQQ", sr, ch, orig, len(frames)) + body + struct.pack("<IIQ", delay, 0, orig)
+        ref, _, _ = O.decode(data)
+        dec = glc_amd.Decoder(ch, sr).decode(glc_amd.EncodedAudio.from_bytes(data))
+        assert dec.size == ref.size and np.array_equal(bits(dec), bits(ref))
+    # fewer channel vectors than header.channels: the reference panics; here GLC_EFORMAT
+    data = struct.pack("<IHQQ", 44100, 2, 100, 1) + struct.pack("<QQ", 1, 0) + struct.pack("<Qf", 1, 0.5) + b"\x00" \
+        + struct.pack("<IIQ", 512, 0, 100)
+    with pytest.raises(glc_amd.GlcError) as e:
+        glc_amd.Decoder(2, 44100).decode(glc_amd.EncodedAudio.from_bytes(data))
+    assert e.value.code == -4

@@ -166,3 +166,30 @@ def test_decoded_len():
         enc = glc_amd.EncodedAudio.from_bytes(data)
         dec, _, _ = O.decode(data)
         assert glc_amd.lib.glc_decoded_len(enc._h) == dec.size
+
+
+def test_container_fuzz_never_crashes():
+    """f1: the reader trusts no length field.  Random mutations of a valid stream either fail with
+    GLC_EFORMAT or yield a stream that re-serialises to a fixed point (serialise(deserialise(x))
+    is stable), and never crash or allocate absurdly."""
+    from hypothesis import given, settings, strategies as st
+    base = _golden_bytes()[0]
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.lists(st.tuples(st.integers(0, len(base) - 1), st.integers(0, 255)), min_size=1, max_size=8),
+           st.integers(0, len(base)))
+    def run(muts, cut):
+        b = bytearray(base)
+        for pos, val in muts:
+            b[pos] = val
+        data = bytes(b[:cut]) if cut % 3 == 0 else bytes(b)
+        try:
+            enc = glc_amd.EncodedAudio.from_bytes(data)
+        except glc_amd.GlcError as e:
+            assert e.code == -4
+            return
+        again = enc.to_bytes()
+        assert glc_amd.EncodedAudio.from_bytes(again).to_bytes() == again
+        assert len(again) <= len(data)
+
+    run()
