@@ -441,6 +441,7 @@ hipError_t launch_mdct_forward(const DeviceTables &t, const PcmView &pcm, uint64
   // workgroups: 2 workgroups = 16 waves per CU at BASELINE config 2, with the 128x128 tile's
   // staging cost per MAC; larger batches use 8x8 outputs per lane (half the LDS reads per MAC).
   if (M >= 16384) return k1::launch_sched<128, 128, 16, 3, 0, 8>(t, pcm, frame_begin, M, coef, s);
+  if (M < 4096) return k1::launch_sched<64, 128, 16, 4, 0, 4>(t, pcm, frame_begin, M, coef, s);  // short clips: more workgroups
   return k1::launch_sched<128, 128, 16, 4, 0, 4>(t, pcm, frame_begin, M, coef, s);  // 512 threads, 4x8 per lane
 }
 

@@ -7,8 +7,16 @@
 // K = 2048; the K loop is strictly ascending with ONE accumulator per output, multiply and add
 // are separate instructions (v_pk_mul_f32 / v_pk_add_f32, never an FMA), there is no split-K.
 //
-// The kernel is a template over its tile shape so that tools/k1_tune.hip can time shapes against
-// each other on the GPU; glc_kernels.hip instantiates the one the library ships.
+// What is in this file
+//   k_mdct_fwd_sched   SHIPPED.  Hand-scheduled inline-asm i-steps (step4 / mac2rows), LDS operand
+//                      prefetch, XCD-aware tile map.  glc_kernels.hip launches
+//                      <128,128,16,4,0,4> (512 threads, 4x8 per lane) for 4096 <= M < 16384,
+//                      <128,128,16,3,0,8> (256 threads, 8x8 per lane) for M >= 16384 and
+//                      <64,128,16,4,0,4> for short clips.  ABL / SCALAR / RING are tuning knobs.
+//   k_mdct_fwd         tuning only: the same tiling left to hipcc's scheduler (19-24 T MAC/s).
+//   k_mdct_fwd_dma     tuning only: table tile by LDS-DMA, 3-slot ring (bit-exact, same speed).
+// tools/k1_tune.hip times them against each other and checks every variant bit-for-bit against a
+// naive kernel; profiles/r01_k1_tune_final.txt holds the numbers.
 #pragma once
 #include <hip/hip_runtime.h>
 
