@@ -217,6 +217,29 @@ def main():
                          "note": "host f32 PCM (pageable) -> H2D -> kernels -> device-side compaction -> D2H of "
                                  "pairs -> EncodedAudio; best of 3"}
 
+    # ---- decode of the same batch, device-resident (sparse rows resident -> interleaved PCM in
+    # HBM): D1 sparse IMDCT + window, D2 overlap-add.  Beside the headline, never `value`. ---------
+    decode = None
+    if rank == 0 and world == 1:
+        ea_d = glc_amd.EncodedAudio.from_records(SR, n_samples, CH, d_rec.cpu().numpy())
+        dec = glc_amd.Decoder(CH, SR, device=local_rank)
+        d_all = torch.empty((FRAMES_PER_GPU + 1) * HOP * CH, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        reps = max(5, min(args.steps, 20))
+        dec.decode_device(ea_d, d_all.data_ptr(), d_all.numel())   # includes the one-off upload
+        dec.synchronize()
+        t_d0 = time.perf_counter()
+        for _ in range(reps):
+            dec.decode_device(ea_d, d_all.data_ptr(), d_all.numel())
+        dec.synchronize()
+        d_ms = (time.perf_counter() - t_d0) * 1e3 / reps
+        nnz_row = ea_d.info().total_nnz / (FRAMES_PER_GPU * CH)
+        decode = {"Msamples/s": round(FRAMES_PER_GPU * HOP * CH / (d_ms * 1e-3) / 1e6, 1), "ms": round(d_ms, 4),
+                  "nnz_per_row": round(nnz_row, 1),
+                  "note": "glc_decode_device per call: host canonical-row prep + 3.9 MB upload + D1 + D2 "
+                          "(wall clock); kernels alone are in profiles/"}
+        dec.close()
+
     # ---- CPU baseline: the oracle (a port of src/codec.rs) on this box's cores, rank 0, N=1
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -271,6 +294,7 @@ def main():
             "step_ms_events": round(step_ev_ms, 4),
             "other_sample_rates": other_rates,
             "host_boundary": host_boundary,
+            "decode": decode,
             "gather": gather,
             "encoded": info,
         }

@@ -61,6 +61,7 @@ SIGNATURES = {
     "glc_frames_from_device_records": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint16, C.POINTER(_vp)]),
     "glc_decoded_len": (C.c_uint64, [_vp]),
     "glc_decode": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "glc_decode_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "glc_decode_stream_begin": (C.c_int, [_vp, _vp]),
     "glc_decode_stream_next": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_int)]),

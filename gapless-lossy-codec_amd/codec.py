@@ -267,6 +267,16 @@ class Decoder(_Ctx):
               self._h)
         return out[:got.value]
 
+    def decode_device(self, encoded: EncodedAudio, d_all: int, cap_all: int):
+        """Device-resident decode of the whole un-trimmed stream into device memory at address
+        d_all; returns (start, n): the window Decoder::decode would return (src/codec.rs:756-765).
+        Queued on the context's stream, not synchronised."""
+        start = C.c_uint64()
+        n = C.c_uint64()
+        check(lib.glc_decode_device(self._h, encoded._h, C.c_void_p(d_all), cap_all, C.byref(start), C.byref(n)),
+              self._h)
+        return start.value, n.value
+
     def decode_streaming(self, encoded: EncodedAudio, progress_sender=None) -> Iterator[AudioChunk]:
         """Decoder::decode_streaming — src/codec.rs:595-741: yields AudioChunk until is_last."""
         check(lib.glc_decode_stream_begin(self._h, encoded._h), self._h)

@@ -654,6 +654,47 @@ int glc_decode(glc_ctx *ctx, const glc_frames *in, float *pcm_out, uint64_t cap,
   return GLC_OK;
 }
 
+int glc_decode_device(glc_ctx *ctx, const glc_frames *in, float *d_all, uint64_t cap_all, uint64_t *start,
+                      uint64_t *n_out) {
+  if (!ctx || !in || !d_all) return fail(ctx, GLC_EINVAL, "glc_decode_device: null argument");
+  ctx->stream_open = false;
+  const uint32_t ch = in->channels;
+  const uint64_t all = (in->n_frames + 1) * static_cast<uint64_t>(glc::kHop) * ch;
+  if (cap_all < all) return fail(ctx, GLC_EINVAL, "glc_decode_device: output buffer too small");
+  uint64_t s0 = 0, n = all;
+  if (n > in->encoder_delay) {
+    s0 = in->encoder_delay;
+    n -= in->encoder_delay;
+  }
+  if (n > in->original_length) n = in->original_length;
+  if (start) *start = s0;
+  if (n_out) *n_out = n;
+  int rc = decode_prepare(ctx, in);
+  if (rc != GLC_OK) return rc;
+  DeviceGuard guard(ctx->device);
+  const uint64_t nf = in->n_frames;
+  const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(kDecodeChunkFrames, nf));
+  const size_t slot = static_cast<size_t>(ch) * glc::kFrame;
+  GLC_HIP(ctx, ctx->blocks.reserve((chunk + 1) * slot * sizeof(float)));
+  float *blocks = static_cast<float *>(ctx->blocks.p);
+  GLC_HIP(ctx, hipMemsetAsync(blocks, 0, slot * sizeof(float), ctx->stream));  // overlap = 0.0, :601
+  uint64_t f0 = 0;
+  do {
+    const uint64_t nchunk = std::min(chunk, nf - f0);
+    const bool last = f0 + nchunk == nf;
+    if (nchunk)
+      GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, static_cast<uint32_t>(f0 * ch),
+                                          static_cast<uint32_t>(nchunk * ch), ch, blocks + slot, ctx->stream));
+    GLC_HIP(ctx, glc::launch_overlap_add(blocks, static_cast<int64_t>(f0) - 1, nf, ch, f0, f0 + nchunk + (last ? 1 : 0),
+                                         d_all + f0 * glc::kHop * ch, ctx->stream));
+    if (!last)
+      GLC_HIP(ctx, hipMemcpyAsync(blocks, blocks + nchunk * slot, slot * sizeof(float), hipMemcpyDeviceToDevice,
+                                  ctx->stream));
+    f0 += nchunk;
+  } while (f0 < nf);
+  return GLC_OK;
+}
+
 int glc_decode_stream_begin(glc_ctx *ctx, const glc_frames *in) {
   if (!ctx || !in) return fail(ctx, GLC_EINVAL, "glc_decode_stream_begin: null argument");
   ctx->stream_open = false;

@@ -153,6 +153,14 @@ uint64_t glc_decoded_len(const glc_frames *in);
 int glc_decode(glc_ctx *ctx, const glc_frames *in, float *pcm_out, uint64_t cap,
                uint64_t *n_out);
 
+/* Device-resident decode: the whole un-trimmed stream decode_streaming emits ((n_frames + 1) *
+ * 1024 * channels samples, src/codec.rs:688-732) is written to the device buffer d_all (capacity
+ * cap_all samples); *start / *n_out give the gapless-trimmed window Decoder::decode would return
+ * (:756-765) inside it.  Work is queued on glc_ctx_stream(ctx) and NOT synchronised, except for
+ * the one-off upload of the sparse rows. */
+int glc_decode_device(glc_ctx *ctx, const glc_frames *in, float *d_all, uint64_t cap_all,
+                      uint64_t *start, uint64_t *n_out);
+
 /* Decoder::decode_streaming src/codec.rs:595-741: un-trimmed output delivered in chunks of at
  * least FRAMES_PER_CHUNK*1024*channels samples (AudioChunk, :81-85).  `begin` decodes on the
  * device; `next` copies the next chunk (returns its size through n_out, sets *is_last on the

@@ -422,3 +422,23 @@ def test_decode_degenerate_streams(torch_cuda):
     with pytest.raises(glc_amd.GlcError) as e:
         glc_amd.Decoder(2, 44100).decode(glc_amd.EncodedAudio.from_bytes(data))
     assert e.value.code == -4
+
+
+def test_device_resident_decode(torch_cuda):
+    """glc_decode_device writes the un-trimmed stream into caller-owned device memory; its
+    trimmed window equals Decoder::decode bit for bit (multi-chunk: > 4096 frames)."""
+    sr, ch = 48000, 2
+    x = np.concatenate([gen_chord(sr, ch, 4500 * 1024, n_tones=5), gen_noise(sr, ch, 0.3, 4)])
+    enc = glc_amd.Encoder(sr).encode(x, ch)
+    nf = enc.info().n_frames
+    assert nf > 4096 and 0 < enc.info().n_raw_frames < nf
+    dec = glc_amd.Decoder(ch, sr)
+    host = dec.decode(enc)
+    d_all = torch_cuda.empty((nf + 1) * 1024 * ch, dtype=torch_cuda.float32, device="cuda")
+    torch_cuda.cuda.synchronize()
+    start, n = dec.decode_device(enc, d_all.data_ptr(), d_all.numel())
+    dec.synchronize()
+    assert (start, n) == (512, x.size)
+    assert np.array_equal(bits(d_all.cpu().numpy()[start:start + n]), bits(host))
+    with pytest.raises(glc_amd.GlcError):
+        dec.decode_device(enc, d_all.data_ptr(), d_all.numel() - 1)
