@@ -185,7 +185,10 @@ def main():
         gather = {"ms": round(g_ms, 3), "bytes_to_root": int(rec_bytes * FRAMES_PER_GPU * (world - 1)),
                   "backend": "nccl(rccl over xGMI)" if backend == "nccl" else backend}
         if rank == 0:  # the gathered records assemble into one valid stream of world x 4096 frames
-            ea = glc_amd.EncodedAudio.from_records(SR, n_samples, CH, allrec.cpu().numpy())
+            if allrec.is_cuda:  # compact on the root's device, only the bitstream payload crosses PCIe
+                ea = enc.frames_from_device_records(allrec.data_ptr(), FRAMES_PER_GPU * world, n_samples, CH)
+            else:
+                ea = glc_amd.EncodedAudio.from_records(SR, n_samples, CH, allrec.numpy())
             gather["assembled_frames"] = int(ea.info().n_frames)
             gather["assembled_raw_frames"] = int(ea.info().n_raw_frames)
         if rank == 0:

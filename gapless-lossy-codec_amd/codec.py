@@ -258,8 +258,22 @@ class Decoder(_Ctx):
         super().__init__(sample_rate, device)
         self.channels = channels
 
+    @staticmethod
+    def _progress(sender, kind: str, value) -> None:
+        """Progress (src/codec.rs:71-79) delivered to an optional callable(kind, value) in place of
+        the crossbeam Sender: kinds 'Status', 'Decoding', 'Complete' as sent at :609, :713, :736."""
+        if sender is not None:
+            sender(kind, value)
+
     def decode(self, encoded: EncodedAudio, progress_sender=None) -> np.ndarray:
         """Decoder::decode — src/codec.rs:744-768 (overlap-add, gapless trim)."""
+        if progress_sender is not None:  # the reference decodes through decode_streaming (:747)
+            chunks = [c.samples for c in self.decode_streaming(encoded, progress_sender)]
+            allv = np.concatenate(chunks) if chunks else np.empty(0, np.float32)
+            g = encoded.gapless_info
+            if allv.size > g.encoder_delay:
+                allv = allv[g.encoder_delay:]
+            return allv[:g.original_length].copy()
         n = lib.glc_decoded_len(encoded._h)
         out = np.empty(n, np.float32)
         got = C.c_uint64()
@@ -279,17 +293,27 @@ class Decoder(_Ctx):
 
     def decode_streaming(self, encoded: EncodedAudio, progress_sender=None) -> Iterator[AudioChunk]:
         """Decoder::decode_streaming — src/codec.rs:595-741: yields AudioChunk until is_last."""
+        import time as _time
+        t0 = _time.perf_counter()
+        total_frames = encoded.info().n_frames
+        self._progress(progress_sender, "Status", f"Starting streaming decode of {total_frames} frames")
         check(lib.glc_decode_stream_begin(self._h, encoded._h), self._h)
         ch = encoded.header.channels
         cap = FRAMES_PER_CHUNK * HOP_SIZE * ch  # the last chunk is < 500 frames + the tail hop
+        done = 0
         while True:
             buf = np.empty(cap, np.float32)
             n = C.c_uint64()
             last = C.c_int()
             check(lib.glc_decode_stream_next(self._h, buf.ctypes.data_as(C.c_void_p), cap, C.byref(n),
                                              C.byref(last)), self._h)
+            done += FRAMES_PER_CHUNK
+            if not last.value and total_frames:
+                self._progress(progress_sender, "Decoding", min(done, total_frames) / total_frames * 100.0)
             yield AudioChunk(buf[:n.value].copy(), bool(last.value))
             if last.value:
+                self._progress(progress_sender, "Complete",
+                               f"Decoded {total_frames} frames in {_time.perf_counter() - t0:.2f}s")
                 return
 
 

@@ -442,3 +442,18 @@ def test_device_resident_decode(torch_cuda):
     assert np.array_equal(bits(d_all.cpu().numpy()[start:start + n]), bits(host))
     with pytest.raises(glc_amd.GlcError):
         dec.decode_device(enc, d_all.data_ptr(), d_all.numel() - 1)
+
+
+def test_progress_messages(torch_cuda):
+    """Progress (src/codec.rs:71-79) as the streaming decoder sends it (:609, :713, :736)."""
+    sr, ch = 44100, 1
+    x = gen_chord(sr, ch, 1100 * 1024, n_tones=3)
+    enc = glc_amd.Encoder(sr).encode(x, ch)
+    seen = []
+    dec = glc_amd.Decoder(ch, sr)
+    out = dec.decode(enc, lambda kind, value: seen.append((kind, value)))
+    assert np.array_equal(bits(out), bits(dec.decode(enc)))
+    kinds = [k for k, _ in seen]
+    assert kinds[0] == "Status" and kinds[-1] == "Complete" and kinds.count("Decoding") == 2
+    assert seen[0][1] == "Starting streaming decode of 1100 frames"
+    assert all(0.0 < v <= 100.0 for k, v in seen if k == "Decoding")
