@@ -113,25 +113,34 @@ __global__ __launch_bounds__(256) void k_quantize(DeviceTables tb, const float *
         const unsigned lo = tb.edges[b], hi = tb.edges[b + 1];
         float ss = 0.0f;
         unsigned i = lo;
+        // head: up to 3 bins until the index is 16-byte aligned
+        for (; i < hi && (i & 3u); ++i) ss = add_rn(ss, sq[i]);
+        // body: 8 bins per step as two ds_read_b128, the next step's reads in flight while the
+        // current 8 adds (a dependent chain, the reference's order) execute; ping-pong registers
         if (i + 8 <= hi) {
-          // software pipeline: the next 8 LDS reads are in flight while the current 8 adds (a
-          // dependent chain, the reference's order) execute
-          float v[8], nv[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = sq[i + j];
-          for (; i + 16 <= hi; i += 8) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) nv[j] = sq[i + 8 + j];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ss = add_rn(ss, v[j]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = nv[j];
+          const float4 *q4 = reinterpret_cast<const float4 *>(sq);
+          float4 a0 = q4[i >> 2], a1 = q4[(i >> 2) + 1];
+          while (i + 16 <= hi) {
+            const float4 b0 = q4[(i >> 2) + 2], b1 = q4[(i >> 2) + 3];
+            ss = add_rn(ss, a0.x); ss = add_rn(ss, a0.y); ss = add_rn(ss, a0.z); ss = add_rn(ss, a0.w);
+            ss = add_rn(ss, a1.x); ss = add_rn(ss, a1.y); ss = add_rn(ss, a1.z); ss = add_rn(ss, a1.w);
+            i += 8;
+            if (i + 16 <= hi) {
+              a0 = q4[(i >> 2) + 2];
+              a1 = q4[(i >> 2) + 3];
+              ss = add_rn(ss, b0.x); ss = add_rn(ss, b0.y); ss = add_rn(ss, b0.z); ss = add_rn(ss, b0.w);
+              ss = add_rn(ss, b1.x); ss = add_rn(ss, b1.y); ss = add_rn(ss, b1.z); ss = add_rn(ss, b1.w);
+              i += 8;
+            } else {
+              a0 = b0;
+              a1 = b1;
+            }
           }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) ss = add_rn(ss, v[j]);
+          ss = add_rn(ss, a0.x); ss = add_rn(ss, a0.y); ss = add_rn(ss, a0.z); ss = add_rn(ss, a0.w);
+          ss = add_rn(ss, a1.x); ss = add_rn(ss, a1.y); ss = add_rn(ss, a1.z); ss = add_rn(ss, a1.w);
           i += 8;
         }
-        for (; i < hi; ++i) ss = add_rn(ss, sq[i]);
+        for (; i < hi; ++i) ss = add_rn(ss, sq[i]);  // tail: fewer than 8 bins
         const float energy = sqrtf(ss / tb.band_len[b]);                                  // :214-215
         sbase[w][r][b] = mul_rn(mul_rn(mul_rn(energy, 0.01f), tb.cf), tb.band_pf[b]);      // :223
       }
