@@ -265,7 +265,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "Msamples/s encoded (48 kHz stereo batch)",
+            "metric": "Msamples/s encoded (48 kHz stereo batch) at 1/2/4/8 GPUs; % HBM roofline",
             "value": round(value, 2),
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -290,7 +290,7 @@ def main():
                                  "4096 flop/sample = 2048 separately rounded mul + 2048 add. Bit-exact "
                                  "parity forbids FMA, so a VALU-only kernel tops out at 50 % of this peak."},
             "roofline_hbm": {"bound": "hbm", "achieved": round(k1_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(k1_gbs / HBM_PEAK_GBS, 5),
+                             "frac": round(k1_gbs / HBM_PEAK_GBS, 5), "pct_hbm_roofline": round(100 * k1_gbs / HBM_PEAK_GBS, 3),
                              "note": "BASELINE metric's '% HBM roofline': 6.006 algorithmic B/sample; the "
                                      "path is compute-bound (SURVEY F4), cap under parity = 1.44 %"},
             "cpu_baseline": cpu,
