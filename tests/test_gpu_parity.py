@@ -457,3 +457,16 @@ def test_progress_messages(torch_cuda):
     assert kinds[0] == "Status" and kinds[-1] == "Complete" and kinds.count("Decoding") == 2
     assert seen[0][1] == "Starting streaming decode of 1100 frames"
     assert all(0.0 < v <= 100.0 for k, v in seen if k == "Decoding")
+
+
+@pytest.mark.parametrize("ch", [7, 16, 33])
+def test_unusual_channel_counts(torch_cuda, ch):
+    """Row = frame * ch + c for any channel count (tiles start mid-frame when ch does not divide 128)."""
+    sr = 48000
+    x = gen_chord(sr, ch, 3000 + 17 * ch, n_tones=3)
+    ref = O.encode(x, sr, ch)
+    enc = glc_amd.Encoder(sr).encode(x, ch)
+    assert enc.to_bytes() == ref.glc
+    dec = glc_amd.Decoder(ch, sr).decode(enc)
+    dref, _, _ = O.decode(ref.glc)
+    assert np.array_equal(bits(dec), bits(dref))
