@@ -481,7 +481,17 @@ namespace {
 // canonical (strictly ascending, idx < 1024 — what the encoder emits); other lists are
 // canonicalised on the host with the reference's dense-array semantics (last write wins,
 // idx >= 1024 ignored, src/codec.rs:659-665) and appended behind the stored pairs.
+int decode_prepare_impl(glc_ctx *ctx, const glc_frames *in);
+
 int decode_prepare(glc_ctx *ctx, const glc_frames *in) {
+  try {  // no C++ exception may cross the C ABI
+    return decode_prepare_impl(ctx, in);
+  } catch (const std::bad_alloc &) {
+    return fail(ctx, GLC_ENOMEM, "glc_decode: host allocation failed");
+  }
+}
+
+int decode_prepare_impl(glc_ctx *ctx, const glc_frames *in) {
   const uint32_t ch = in->channels;
   if (ch == 0) return fail(ctx, GLC_EINVAL, "glc_decode: header.channels == 0");
   const uint64_t nf = in->n_frames;

@@ -283,7 +283,12 @@ int glc_deserialize(const uint8_t *buf, uint64_t len, glc_frames **out) {
 int glc_save(const glc_frames *f, const char *path) {
   if (!f || !path) return GLC_EINVAL;
   const uint64_t n = glc_serialized_size(f);
-  std::vector<uint8_t> buf(n);
+  std::vector<uint8_t> buf;
+  try {  // no C++ exception may cross the C ABI
+    buf.resize(n);
+  } catch (const std::bad_alloc &) {
+    return GLC_ENOMEM;
+  }
   uint64_t w = 0;
   int rc = glc_serialize(f, buf.data(), n, &w);
   if (rc != GLC_OK) return rc;
@@ -311,7 +316,12 @@ int glc_load(const char *path, glc_frames **out) {
   std::vector<uint8_t> buf;
   uint8_t tmp[1 << 16];
   size_t got;
-  while ((got = std::fread(tmp, 1, sizeof tmp, fp)) > 0) buf.insert(buf.end(), tmp, tmp + got);
+  try {
+    while ((got = std::fread(tmp, 1, sizeof tmp, fp)) > 0) buf.insert(buf.end(), tmp, tmp + got);
+  } catch (const std::bad_alloc &) {
+    std::fclose(fp);
+    return GLC_ENOMEM;
+  }
   std::fclose(fp);
   return glc_deserialize(buf.data(), buf.size(), out);
 }

@@ -32,7 +32,13 @@ int glc_wav_load(const char *path, float **samples, uint64_t *n_samples, uint32_
                  uint16_t *channels) {
   if (!path || !samples || !n_samples || !sample_rate || !channels) return GLC_EINVAL;
   std::vector<uint8_t> f;
-  if (!read_all(path, f)) {
+  bool opened = false;
+  try {  // no C++ exception may cross the C ABI
+    opened = read_all(path, f);
+  } catch (const std::bad_alloc &) {
+    return GLC_ENOMEM;
+  }
+  if (!opened) {
     glc::set_global_error(std::string("glc_wav_load: cannot open ") + path);
     return GLC_EIO;
   }
@@ -102,7 +108,12 @@ int glc_wav_save16(const char *path, const float *samples, uint64_t n_samples, u
     glc::set_global_error("glc_wav_save16: stream too long for a RIFF file");
     return GLC_EINVAL;
   }
-  std::vector<uint8_t> buf(44 + data_bytes);
+  std::vector<uint8_t> buf;
+  try {
+    buf.resize(44 + data_bytes);
+  } catch (const std::bad_alloc &) {
+    return GLC_ENOMEM;
+  }
   auto put32 = [&](size_t at, uint32_t v) { for (int i = 0; i < 4; ++i) buf[at + i] = (v >> (8 * i)) & 0xFF; };
   auto put16 = [&](size_t at, uint16_t v) { buf[at] = v & 0xFF; buf[at + 1] = v >> 8; };
   std::memcpy(&buf[0], "RIFF", 4);
