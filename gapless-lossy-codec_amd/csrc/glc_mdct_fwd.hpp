@@ -8,13 +8,14 @@
 // are separate instructions (v_pk_mul_f32 / v_pk_add_f32, never an FMA), there is no split-K.
 //
 // What is in this file
-//   k_mdct_fwd_sched   SHIPPED.  Hand-scheduled inline-asm i-steps (step4 / mac2rows), LDS operand
-//                      prefetch, XCD-aware tile map.  glc_kernels.hip launches
-//                      <128,128,16,4,0,4> (512 threads, 4x8 per lane) for 4096 <= M < 16384,
+//   k_mdct_fwd_dma     SHIPPED for 4096 <= M < 16384 (BASELINE config 2): 128x128 tile, 512 threads,
+//                      4x8 outputs per lane, table tile copied global -> LDS by LDS-DMA two stages
+//                      ahead (3-slot ring), one counted vmcnt wait per stage.
+//   k_mdct_fwd_sched   SHIPPED for the other sizes.  Hand-scheduled inline-asm i-steps (step4 /
+//                      mac2rows), LDS operand prefetch, XCD-aware tile map, register staging:
 //                      <128,128,16,3,0,8> (256 threads, 8x8 per lane) for M >= 16384 and
-//                      <64,128,16,4,0,4> for short clips.  ABL / SCALAR / RING are tuning knobs.
+//                      <64,128,16,4,0,4> for short clips.  ABL / SCALAR / RING / WLDS are tuning knobs.
 //   k_mdct_fwd         tuning only: the same tiling left to hipcc's scheduler (19-24 T MAC/s).
-//   k_mdct_fwd_dma     tuning only: table tile by LDS-DMA, 3-slot ring (bit-exact, same speed).
 // tools/k1_tune.hip times them against each other and checks every variant bit-for-bit against a
 // naive kernel; profiles/r01_k1_tune_final.txt holds the numbers.
 #pragma once
@@ -412,7 +413,10 @@ __device__ __forceinline__ void mac_step(f32x2 (&acc)[TM][4], const Operands &o)
 // of stage s, so its ds_writes must land before the barrier); 3 = stage s+2 is written at the end
 // of stage s into the slot nobody reads, the barrier publishes the writes of the PREVIOUS stage
 // and needs no LDS wait in front of it.
-template <int BM, int BN, int BK, int MINW, int ABL = 0, int TM = 8, bool SCALAR = false, int RING = 2>
+// WLDS = the window (8 KiB) is copied to LDS once and read from there when a stage is written,
+// instead of 4 global loads per thread and stage.
+template <int BM, int BN, int BK, int MINW, int ABL = 0, int TM = 8, bool SCALAR = false, int RING = 2,
+          bool WLDS = false>
 __global__ __launch_bounds__((BM / TM) * (BN / 8)) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
 void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm, long long frame_begin, unsigned M,
                       float *__restrict__ coef) {
@@ -420,8 +424,11 @@ void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm, long long frame_begin, unsig
   static_assert(!SCALAR || TM == 4, "scalar stream is written for the 4x8 lane tile");
   __shared__ __attribute__((aligned(16))) float As[RING][BK * BM];
   __shared__ __attribute__((aligned(16))) float Bs[RING][BK * BN];
+  __shared__ float Ws[WLDS ? kFrameI : 1];
 
   const int tid = threadIdx.x;
+  if (WLDS)
+    for (int i = tid; i < kFrameI; i += C::kThreads) Ws[i] = tb.window[i];
   // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 says which blocks share an
   // L2).  Give XCD x the contiguous tile range [x*T/8, (x+1)*T/8) in (m_tile, n_tile) order: the
   // PCM rows of an m-tile are then fetched by ONE XCD instead of all eight, and the table rows of
@@ -472,20 +479,21 @@ void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm, long long frame_begin, unsig
 #pragma unroll
     for (int j = 0; j < C::kAPer; ++j) {
       a_raw[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, off0 + j * a_step, 0, 0));
-      a_win[j] = w_ptr[i0 + C::kAStride * j];
+      if (!WLDS) a_win[j] = w_ptr[i0 + C::kAStride * j];
     }
 #pragma unroll
     for (int j = 0; j < C::kBPer; ++j)
       b_stage[j] = *reinterpret_cast<const f32x4 *>(b_ptr + static_cast<size_t>(i0 + C::kBRowsPer * j) * kHopI);
   };
-  auto store_stage = [&](int buf) {
+  auto store_stage = [&](int buf, int i0) {
     // pin the first use of the staged registers behind the stage's math (volatile asm
     // statements keep their order): hipcc otherwise hoists the multiply, and with it the
     // vmcnt wait, into the middle of the stage
 #pragma unroll
     for (int j = 0; j < C::kAPer; ++j) {
-      float r = a_raw[j], w = a_win[j];
+      float r = a_raw[j], w = WLDS ? 0.0f : a_win[j];
       asm volatile("" : "+v"(r), "+v"(w));
+      if (WLDS) w = Ws[i0 + a_i + C::kAStride * j];
       As[buf][(a_i + C::kAStride * j) * BM + a_r] = mul_rn(r, w);  // block[i] = slice[i]*window[i], :480
     }
 #pragma unroll
@@ -515,11 +523,12 @@ void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm, long long frame_begin, unsig
     else lds_wait4(o);
   };
 
+  if (WLDS) __syncthreads();
   load_stage(0);
-  store_stage(0);
+  store_stage(0, 0);
   if (RING == 3) {
     load_stage(BK);
-    store_stage(1);
+    store_stage(1, BK);
   }
   __syncthreads();
 
@@ -566,14 +575,14 @@ void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm, long long frame_begin, unsig
         if (ABL != 2 && ii + 2 < BK) wait(X);
       }
     }
-    if (ABL == 3) store_stage(buf ^ 1);
+    if (ABL == 3) store_stage(buf ^ 1, ((s + 1) & (kStages - 1)) * BK);
     if (ABL == 4) __syncthreads();
     if (ABL == 0) {
       if (RING == 3) {
-        store_stage((s + 2) % 3);
+        store_stage((s + 2) % 3, ((s + 2) & (kStages - 1)) * BK);
         __builtin_amdgcn_s_barrier();  // publishes the writes made one stage ago; no LDS wait
       } else {
-        store_stage(buf ^ 1);
+        store_stage(buf ^ 1, ((s + 1) & (kStages - 1)) * BK);
         __syncthreads();
       }
     }
@@ -598,20 +607,21 @@ void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm, long long frame_begin, unsig
   }
 }
 
-template <int BM, int BN, int BK, int MINW, int ABL = 0, int TM = 8, bool SCALAR = false, int RING = 2>
+template <int BM, int BN, int BK, int MINW, int ABL = 0, int TM = 8, bool SCALAR = false, int RING = 2,
+          bool WLDS = false>
 inline hipError_t launch_sched(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M,
                                float *coef, hipStream_t s) {
   using C = Cfg<BM, BN, BK, TM, 8, 2, MINW>;
   if (M == 0) return hipSuccess;
   const unsigned m_tiles = (M + BM - 1) / BM;
-  hipLaunchKernelGGL((k_mdct_fwd_sched<BM, BN, BK, MINW, ABL, TM, SCALAR, RING>), dim3(m_tiles * C::kNTiles),
+  hipLaunchKernelGGL((k_mdct_fwd_sched<BM, BN, BK, MINW, ABL, TM, SCALAR, RING, WLDS>), dim3(m_tiles * C::kNTiles),
                      dim3(C::kThreads), 0, s, t, pcm,
                      static_cast<long long>(frame_begin), M, coef);
   return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
-// LDS-DMA variant (128x128 tile, 512 threads, 4x8 outputs per lane, 3-slot LDS ring).
+// LDS-DMA kernel (128x128 tile, 512 threads, 4x8 outputs per lane, 3-slot LDS ring).
 // The table tile of stage s+2 is copied global -> LDS by `global_load_lds_dwordx4` while stages s
 // and s+1 compute: two stages of latency budget, no VGPRs and no ds_write for the table.  The PCM
 // tile (needs the window multiply) goes through registers one stage ahead, the window itself sits

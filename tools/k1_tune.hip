@@ -97,6 +97,8 @@ int main(int argc, char **argv) {
   std::vector<Variant> vs = {
       Variant{"sched pk 128x128 bk16 t4x8 w4 512thr (shipped, M < 16384)", k1::launch_sched<128, 128, 16, 4, 0, 4>},
       Variant{"sched pk 128x128 bk16 t8x8 w3 256thr (shipped, M >= 16384)", k1::launch_sched<128, 128, 16, 3, 0, 8>},
+      Variant{"sched pk 128x128 bk16 t4x8 w4 512thr + window in LDS", k1::launch_sched<128, 128, 16, 4, 0, 4, false, 2, true>},
+      Variant{"sched pk 128x128 bk16 t8x8 w3 256thr + window in LDS", k1::launch_sched<128, 128, 16, 3, 0, 8, false, 2, true>},
       Variant{"dma   pk 128x128 bk16 t4x8 w4 512thr ring3 (table by LDS-DMA)", k1::launch_dma<4>},
       Variant{"dma   pk 128x128 ... w3", k1::launch_dma<3>},
       Variant{"  512thr ABL1 (no staging, no barrier)", k1::launch_sched<128, 128, 16, 4, 1, 4>},
