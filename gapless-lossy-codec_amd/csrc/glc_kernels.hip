@@ -447,9 +447,9 @@ hipError_t launch_mdct_forward(const DeviceTables &t, const PcmView &pcm, uint64
   // Shapes measured with tools/k1_tune.hip (profiles/r01_k1_tune_*.txt).  The f32 VALU needs
   // >= 4 waves per SIMD to approach its issue rate, so batches that give fewer than ~8
   // 128x128 tiles per CU use 4x8 outputs per lane (32 accumulators, 93 VGPRs) in 512-thread
-  // workgroups: 2 workgroups = 16 waves per CU at BASELINE config 2, table tile by LDS-DMA;
-  // larger batches use 8x8 outputs per lane (half the LDS reads per MAC), register staging.
-  if (M >= 16384) return k1::launch_sched<128, 128, 16, 3, 0, 8>(t, pcm, frame_begin, M, coef, s);
+  // workgroups: 2 workgroups = 16 waves per CU at BASELINE config 2, table tile by LDS-DMA.
+  // The 8x8-per-lane register-staged kernel measures the same at M >= 16384 (k1_tune), so one
+  // kernel serves every batch of 4096 rows or more; short clips use 64-row tiles.
   if (M < 4096) return k1::launch_sched<64, 128, 16, 4, 0, 4>(t, pcm, frame_begin, M, coef, s);  // short clips: more workgroups
   return k1::launch_dma<4>(t, pcm, frame_begin, M, coef, s);  // 512 threads, 4x8 per lane, table tile by LDS-DMA
 }

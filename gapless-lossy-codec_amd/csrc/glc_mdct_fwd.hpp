@@ -8,13 +8,14 @@
 // are separate instructions (v_pk_mul_f32 / v_pk_add_f32, never an FMA), there is no split-K.
 //
 // What is in this file
-//   k_mdct_fwd_dma     SHIPPED for 4096 <= M < 16384 (BASELINE config 2): 128x128 tile, 512 threads,
+//   k_mdct_fwd_dma     SHIPPED for M >= 4096 rows (BASELINE config 2 = 8192): 128x128 tile, 512 threads,
 //                      4x8 outputs per lane, table tile copied global -> LDS by LDS-DMA two stages
 //                      ahead (3-slot ring), one counted vmcnt wait per stage.
-//   k_mdct_fwd_sched   SHIPPED for the other sizes.  Hand-scheduled inline-asm i-steps (step4 /
-//                      mac2rows), LDS operand prefetch, XCD-aware tile map, register staging:
-//                      <128,128,16,3,0,8> (256 threads, 8x8 per lane) for M >= 16384 and
-//                      <64,128,16,4,0,4> for short clips.  ABL / SCALAR / RING / WLDS are tuning knobs.
+//   k_mdct_fwd_sched   SHIPPED for short clips (M < 4096) as <64,128,16,4,0,4>.  Hand-scheduled
+//                      inline-asm i-steps (step4 / mac2rows), LDS operand prefetch, XCD-aware tile
+//                      map, register staging.  Other shapes and ABL / SCALAR / RING / WLDS are
+//                      tuning knobs (the 8x8-per-lane <128,128,16,3,0,8> ties the DMA kernel at
+//                      M >= 16384).
 //   k_mdct_fwd         tuning only: the same tiling left to hipcc's scheduler (19-24 T MAC/s).
 // tools/k1_tune.hip times them against each other and checks every variant bit-for-bit against a
 // naive kernel; profiles/r01_k1_tune_final.txt holds the numbers.
