@@ -183,7 +183,9 @@ def main():
         torch.cuda.synchronize()
         g_ms = (time.perf_counter() - g0) * 1e3
         gather = {"ms": round(g_ms, 3), "bytes_to_root": int(rec_bytes * FRAMES_PER_GPU * (world - 1)),
-                  "backend": "nccl(rccl over xGMI)" if backend == "nccl" else backend}
+                  "backend": "nccl(rccl over xGMI)" if backend == "nccl" else backend,
+                  # the whole job = K batches + this one gather: throughput with it counted in
+                  "value_including_gather": round(samples_per_step * args.steps / (elapsed + g_ms * 1e-3) / 1e6, 2)}
         if rank == 0:  # the gathered records assemble into one valid stream of world x 4096 frames
             if allrec.is_cuda:  # compact on the root's device, only the bitstream payload crosses PCIe
                 ea = enc.frames_from_device_records(allrec.data_ptr(), FRAMES_PER_GPU * world, n_samples, CH)
