@@ -1,0 +1,202 @@
+// glc.hpp — header-only C++ mirror of the reference's public codec API over the C ABI (glc.h).
+//
+// Same names, argument meaning and results as the Rust items in src/codec.rs of
+// ajcm474/gapless-lossy-codec v0.5.0 (file:line cited per member); `anyhow::Result` becomes an
+// exception (glc::Error, carrying the glc_status code).  Inputs the reference panics on throw
+// glc::Error(GLC_EINVAL).  All arithmetic happens in libglc_hip.so on a gfx950 device.
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "glc.h"
+
+namespace glc {
+
+constexpr unsigned FRAME_SIZE = GLC_FRAME_SIZE;              // src/codec.rs:15
+constexpr unsigned HOP_SIZE = GLC_HOP_SIZE;                  // src/codec.rs:16
+constexpr unsigned FRAMES_PER_CHUNK = GLC_FRAMES_PER_CHUNK;  // src/codec.rs:18
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string &what) : std::runtime_error(what), code(c) {}
+};
+
+namespace detail {
+inline void check(int rc, const glc_ctx *ctx = nullptr) {
+  if (rc != GLC_OK) {
+    const char *m = glc_last_error(ctx);
+    if (!m || !*m) m = glc_last_error(nullptr);
+    throw Error(rc, m ? m : "glc error");
+  }
+}
+}  // namespace detail
+
+struct AudioHeader {  // src/codec.rs:39-45
+  uint32_t sample_rate;
+  uint16_t channels;
+  uint64_t total_samples;
+};
+struct GaplessInfo {  // src/codec.rs:47-53
+  uint32_t encoder_delay, padding;
+  uint64_t original_length;
+};
+struct EncodedFrame {  // src/codec.rs:56-69
+  std::vector<std::vector<std::pair<uint16_t, int16_t>>> sparse_coeffs_per_channel;
+  std::vector<float> scale_factors;
+  bool has_raw_pcm = false;  // Option<Vec<i16>>
+  std::vector<int16_t> raw_pcm;
+};
+struct AudioChunk {  // src/codec.rs:81-85
+  std::vector<float> samples;
+  bool is_last;
+};
+
+// EncodedAudio (src/codec.rs:31-37): owns the library-side object; frames are read on demand.
+class EncodedAudio {
+ public:
+  EncodedAudio() = default;
+  explicit EncodedAudio(glc_frames *h) : h_(h) {}
+  EncodedAudio(EncodedAudio &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+  EncodedAudio &operator=(EncodedAudio &&o) noexcept {
+    if (this != &o) {
+      glc_frames_free(h_);
+      h_ = o.h_;
+      o.h_ = nullptr;
+    }
+    return *this;
+  }
+  EncodedAudio(const EncodedAudio &) = delete;
+  EncodedAudio &operator=(const EncodedAudio &) = delete;
+  ~EncodedAudio() { glc_frames_free(h_); }
+
+  AudioHeader header() const {
+    const glc_info i = info();
+    return {i.sample_rate, i.channels, i.total_samples};
+  }
+  GaplessInfo gapless_info() const {
+    const glc_info i = info();
+    return {i.encoder_delay, i.padding, i.original_length};
+  }
+  uint64_t n_frames() const { return info().n_frames; }
+  EncodedFrame frame(uint64_t f) const {
+    EncodedFrame out;
+    if (glc_frame_is_raw(h_, f) == 1) {
+      uint64_t n = 0;
+      detail::check(glc_frame_raw(h_, f, nullptr, 0, &n));
+      out.has_raw_pcm = true;
+      out.raw_pcm.resize(n);
+      detail::check(glc_frame_raw(h_, f, out.raw_pcm.data(), n, &n));
+    }
+    for (uint32_t c = 0;; ++c) {
+      uint32_t n = 0;
+      if (glc_frame_sparse(h_, f, c, nullptr, nullptr, 0, &n) != GLC_OK) break;
+      std::vector<uint16_t> idx(n);
+      std::vector<int16_t> q(n);
+      detail::check(glc_frame_sparse(h_, f, c, idx.data(), q.data(), n, &n));
+      out.sparse_coeffs_per_channel.emplace_back();
+      for (uint32_t j = 0; j < n; ++j) out.sparse_coeffs_per_channel.back().emplace_back(idx[j], q[j]);
+    }
+    for (uint32_t c = 0;; ++c) {
+      float s;
+      if (glc_frame_scale(h_, f, c, &s) != GLC_OK) break;
+      out.scale_factors.push_back(s);
+    }
+    return out;
+  }
+  // bincode::serialize / deserialize of the struct (what save_encoded / load_encoded write)
+  std::vector<uint8_t> to_bytes() const {
+    std::vector<uint8_t> b(glc_serialized_size(h_));
+    uint64_t w = 0;
+    detail::check(glc_serialize(h_, b.data(), b.size(), &w));
+    return b;
+  }
+  static EncodedAudio from_bytes(const uint8_t *p, uint64_t n) {
+    glc_frames *h = nullptr;
+    detail::check(glc_deserialize(p, n, &h));
+    return EncodedAudio(h);
+  }
+  const glc_frames *handle() const { return h_; }
+
+ private:
+  glc_info info() const {
+    glc_info i{};
+    detail::check(glc_frames_info(h_, &i));
+    return i;
+  }
+  glc_frames *h_ = nullptr;
+};
+
+class Encoder {
+ public:
+  // Encoder::new(sample_rate: u32) — src/codec.rs:406
+  explicit Encoder(uint32_t sample_rate, int device = 0) { detail::check(glc_ctx_create(device, sample_rate, &ctx_)); }
+  ~Encoder() { glc_ctx_destroy(ctx_); }
+  Encoder(const Encoder &) = delete;
+  Encoder &operator=(const Encoder &) = delete;
+  // encode(&mut self, samples: &[f32], channels: u16) -> Result<EncodedAudio> — src/codec.rs:421
+  EncodedAudio encode(const float *samples, uint64_t n_samples, uint16_t channels) {
+    glc_frames *h = nullptr;
+    detail::check(glc_encode(ctx_, samples, n_samples, channels, &h), ctx_);
+    return EncodedAudio(h);
+  }
+  EncodedAudio encode(const std::vector<float> &samples, uint16_t channels) {
+    return encode(samples.data(), samples.size(), channels);
+  }
+  glc_ctx *ctx() { return ctx_; }
+
+ private:
+  glc_ctx *ctx_ = nullptr;
+};
+
+class Decoder {
+ public:
+  // Decoder::new(channels: usize, sample_rate: u32) — src/codec.rs:581; `channels` is accepted and
+  // ignored like the reference (the stream's header decides)
+  Decoder(size_t /*channels*/, uint32_t sample_rate, int device = 0) {
+    detail::check(glc_ctx_create(device, sample_rate, &ctx_));
+  }
+  ~Decoder() { glc_ctx_destroy(ctx_); }
+  Decoder(const Decoder &) = delete;
+  Decoder &operator=(const Decoder &) = delete;
+  // decode(&mut self, &EncodedAudio, _) -> Result<Vec<f32>> — src/codec.rs:744
+  std::vector<float> decode(const EncodedAudio &encoded) {
+    std::vector<float> out(glc_decoded_len(encoded.handle()));
+    uint64_t n = 0;
+    detail::check(glc_decode(ctx_, encoded.handle(), out.data(), out.size(), &n), ctx_);
+    out.resize(n);
+    return out;
+  }
+  // decode_streaming(&mut self, Arc<EncodedAudio>, _) -> Receiver<AudioChunk> — src/codec.rs:595:
+  // the receiver becomes a callback invoked once per chunk, in order, the last one with is_last
+  void decode_streaming(const EncodedAudio &encoded, const std::function<void(AudioChunk &&)> &on_chunk) {
+    detail::check(glc_decode_stream_begin(ctx_, encoded.handle()), ctx_);
+    const uint64_t cap = static_cast<uint64_t>(FRAMES_PER_CHUNK) * HOP_SIZE * encoded.header().channels;
+    for (;;) {
+      AudioChunk c{std::vector<float>(cap), false};
+      uint64_t n = 0;
+      int last = 0;
+      detail::check(glc_decode_stream_next(ctx_, c.samples.data(), cap, &n, &last), ctx_);
+      c.samples.resize(n);
+      c.is_last = last != 0;
+      on_chunk(std::move(c));
+      if (last) return;
+    }
+  }
+
+ private:
+  glc_ctx *ctx_ = nullptr;
+};
+
+// save_encoded / load_encoded — src/codec.rs:774-786
+inline void save_encoded(const EncodedAudio &e, const std::string &path) { detail::check(glc_save(e.handle(), path.c_str())); }
+inline EncodedAudio load_encoded(const std::string &path) {
+  glc_frames *h = nullptr;
+  detail::check(glc_load(path.c_str(), &h));
+  return EncodedAudio(h);
+}
+
+}  // namespace glc

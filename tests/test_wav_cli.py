@@ -116,3 +116,43 @@ def test_cli_encode_decode_matches_oracle(tmp_path):
     r = subprocess.run([CLI, str(tmp_path / "nope.wav"), str(wav)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "Saved" in r.stdout
     assert subprocess.run([CLI, "-d", str(tmp_path / "song.glc")], capture_output=True).returncode == 2
+
+
+def test_cpp_mirror_header_compiles_standalone(tmp_path):
+    """include/glc.hpp is self-contained C++17 (no HIP headers, no torch) and warning-free."""
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "glc.hpp"\nint main() { return sizeof(glc::Encoder) + sizeof(glc::Decoder) == 0; }\n')
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only",
+                        "-I", os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ch,family", [(1, "tone"), (2, "mixed"), (2, "noise")])
+def test_cpp_mirror_roundtrip_matches_oracle(tmp_path, ch, family):
+    """glc::Encoder / glc::Decoder / save_encoded / load_encoded / decode_streaming (include/glc.hpp,
+    the C++ twin of src/codec.rs's public API) in a process with no Python and no torch."""
+    import json
+    exe = os.path.join(ROOT, "build", "glc_cpp_roundtrip")
+    assert os.path.exists(exe), "build/glc_cpp_roundtrip missing: run __graft_entry__.build()"
+    sr = 44100
+    if family == "tone":
+        x = gen_tone("sine", 440.0, sr, ch, 1.3)
+    elif family == "noise":
+        x = gen_noise(sr, ch, 0.4, 9)                     # raw-PCM fallback frames
+    else:
+        x = np.concatenate([gen_tone("square", 220.0, sr, ch, 12.0), gen_noise(sr, ch, 0.2, 3)])  # > 1 chunk
+    (tmp_path / "in.f32").write_bytes(np.ascontiguousarray(x, np.float32).tobytes())
+    r = subprocess.run([exe, str(tmp_path / "in.f32"), str(sr), str(ch), str(tmp_path / "o.glc"),
+                        str(tmp_path / "o.f32")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout)
+    ref = O.encode(x, sr, ch)
+    assert (tmp_path / "o.glc").read_bytes() == ref.glc
+    dref, _, _ = O.decode(ref.glc)
+    got = np.frombuffer((tmp_path / "o.f32").read_bytes(), np.float32)
+    assert got.size == dref.size == info["decoded"] and np.array_equal(got.view(np.uint32), dref.view(np.uint32))
+    assert info["n_frames"] == ref.n_frames and info["original_length"] == x.size
+    assert info["chunks"] == -(-ref.n_frames // 500)
+    if family == "noise":
+        assert info["raw_frames"] > 0
