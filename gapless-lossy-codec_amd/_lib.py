@@ -83,6 +83,13 @@ SIGNATURES = {
                                C.POINTER(C.c_uint16)]),
     "glc_wav_save16": (C.c_int, [C.c_char_p, _vp, C.c_uint64, C.c_uint32, C.c_uint16]),
     "glc_free": (None, [_vp]),
+    "glc_flac_encode": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.c_uint16, C.c_uint8, C.POINTER(_vp),
+                                  C.POINTER(C.c_uint64)]),
+    "glc_flac_save": (C.c_int, [C.c_char_p, _vp, C.c_uint64, C.c_uint32, C.c_uint16, C.c_uint8]),
+    "glc_flac_load": (C.c_int, [C.c_char_p, C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
+                                C.POINTER(C.c_uint16)]),
+    "glc_flac_decode": (C.c_int, [_vp, C.c_uint64, C.POINTER(_vp), C.POINTER(C.c_uint64),
+                                  C.POINTER(C.c_uint32), C.POINTER(C.c_uint16)]),
     "glc_version": (C.c_char_p, []),
 }
 

@@ -348,3 +348,78 @@ def export_to_wav(path, samples, sample_rate: int, channels: int) -> None:
     """audio::export_to_wav (src/audio.rs:100-132): 16-bit PCM."""
     s = np.ascontiguousarray(samples, np.float32).reshape(-1)
     check(lib.glc_wav_save16(str(path).encode(), s.ctypes.data_as(C.c_void_p), s.size, sample_rate, channels))
+
+
+def _take_f32(ptr, n):
+    try:
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(n,)).copy() if n \
+            else np.empty(0, np.float32)
+    finally:
+        lib.glc_free(ptr)
+
+
+def encode_flac_with_level(samples, sample_rate: int, channels: int, compression_level: int) -> bytes:
+    """flac::encode_flac_with_level (src/flac.rs:947-1053): the reference's own FLAC encoder."""
+    s = np.ascontiguousarray(samples, np.float32).reshape(-1)
+    if not 0 <= int(compression_level) <= 255 or not 0 <= int(channels) <= 0xFFFF:
+        raise GlcError(-1, "compression_level is a u8 and channels a u16 in the reference")
+    ptr = C.c_void_p()
+    n = C.c_uint64()
+    check(lib.glc_flac_encode(s.ctypes.data_as(C.c_void_p), s.size, sample_rate, channels, compression_level,
+                              C.byref(ptr), C.byref(n)))
+    try:
+        return C.string_at(ptr, n.value)
+    finally:
+        lib.glc_free(ptr)
+
+
+def encode_flac(samples, sample_rate: int, channels: int) -> bytes:
+    """flac::encode_flac (src/flac.rs:1056-1063): compression level 5."""
+    return encode_flac_with_level(samples, sample_rate, channels, 5)
+
+
+def export_to_flac_with_level(path, samples, sample_rate: int, channels: int, compression_level: int) -> None:
+    """flac::export_to_flac_with_level (src/flac.rs:1066-1077)."""
+    s = np.ascontiguousarray(samples, np.float32).reshape(-1)
+    check(lib.glc_flac_save(str(path).encode(), s.ctypes.data_as(C.c_void_p), s.size, sample_rate, channels,
+                            compression_level))
+
+
+def export_to_flac(path, samples, sample_rate: int, channels: int) -> None:
+    """audio::export_to_flac (src/audio.rs:87-96) = flac::export_to_flac (src/flac.rs:1080-1087)."""
+    export_to_flac_with_level(path, samples, sample_rate, channels, 5)
+
+
+def load_flac(path):
+    """audio::load_flac (src/audio.rs:68-85) -> (samples f32 interleaved, sample_rate, channels)."""
+    ptr = C.c_void_p()
+    n = C.c_uint64()
+    sr = C.c_uint32()
+    ch = C.c_uint16()
+    check(lib.glc_flac_load(str(path).encode(), C.byref(ptr), C.byref(n), C.byref(sr), C.byref(ch)))
+    return _take_f32(ptr, n.value), sr.value, ch.value
+
+
+def decode_flac(data: bytes):
+    """In-memory form of load_flac."""
+    ptr = C.c_void_p()
+    n = C.c_uint64()
+    sr = C.c_uint32()
+    ch = C.c_uint16()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data) if data else (C.c_uint8 * 1)()
+    check(lib.glc_flac_decode(C.cast(buf, C.c_void_p), len(data), C.byref(ptr), C.byref(n), C.byref(sr), C.byref(ch)))
+    return _take_f32(ptr, n.value), sr.value, ch.value
+
+
+def load_audio_file_lossless(path):
+    """audio::load_audio_file_lossless (src/audio.rs:19-36): dispatch on the lower-cased extension."""
+    import os
+    ext = os.path.splitext(str(path))[1]
+    if not ext:
+        raise GlcError(-1, "No file extension")
+    ext = ext[1:].lower()
+    if ext == "wav":
+        return load_wav(path)
+    if ext == "flac":
+        return load_flac(path)
+    raise GlcError(-1, f"Unsupported file format: {ext}")

@@ -205,6 +205,28 @@ int glc_wav_save16(const char *path, const float *samples, uint64_t n_samples, u
                    uint16_t channels);
 void glc_free(void *p);
 
+/* ---- FLAC file I/O twin (src/flac.rs, src/audio.rs:68-96; host only, no device) ----------- */
+
+/* encode_flac_with_level src/flac.rs:947-1053 (encode_flac :1056-1063 is level 5): the reference's
+ * own encoder, byte for byte - 16-bit, (s * 32767).clamp(-32768, 32767) as i16, block 1152
+ * (levels 0-2) or 4096, verbatim (level 0) or fixed predictor of order 1/2/3/3/4.. by level,
+ * partitioned Rice with 4-bit parameters, independent channels, STREAMINFO with the MD5 of the
+ * samples.  GLC_EINVAL for < 16 samples per channel, level > 8 (the reference's two Err cases)
+ * and channels == 0 (a division by zero there).  *out is malloc'd; release it with glc_free. */
+int glc_flac_encode(const float *samples, uint64_t n_samples, uint32_t sample_rate,
+                    uint16_t channels, uint8_t level, uint8_t **out, uint64_t *out_len);
+/* export_to_flac_with_level src/flac.rs:1066-1077 (export_to_flac :1080-1087 is level 5). */
+int glc_flac_save(const char *path, const float *samples, uint64_t n_samples, uint32_t sample_rate,
+                  uint16_t channels, uint8_t level);
+/* load_flac src/audio.rs:68-85 (the reference delegates to the claxon crate): any RFC 9639
+ * stream - constant / verbatim / fixed / LPC subframes, left-side / side-right / mid-side stereo,
+ * both Rice code books, wasted bits - with both CRCs checked; samples become s / 2^(bits-1).
+ * Returns a malloc'd interleaved buffer; release it with glc_free. */
+int glc_flac_load(const char *path, float **samples, uint64_t *n_samples, uint32_t *sample_rate,
+                  uint16_t *channels);
+int glc_flac_decode(const uint8_t *buf, uint64_t len, float **samples, uint64_t *n_samples,
+                    uint32_t *sample_rate, uint16_t *channels);
+
 /* ---- tables (for inspection / parity tests) ---------------------------------------------- */
 
 /* Copies of the host tables of a context: MdctTables.cos_table [1024*2048] (row k), window

@@ -199,4 +199,64 @@ inline EncodedAudio load_encoded(const std::string &path) {
   return EncodedAudio(h);
 }
 
+
+// ---- src/audio.rs + src/flac.rs twins (host only) -----------------------------------------------
+struct LoadedAudio {  // the (Vec<f32>, u32, u16) tuple of load_audio_file_lossless
+  std::vector<float> samples;
+  uint32_t sample_rate;
+  uint16_t channels;
+};
+namespace detail {
+inline LoadedAudio take(float *p, uint64_t n, uint32_t sr, uint16_t ch) {
+  LoadedAudio a{std::vector<float>(p, p + n), sr, ch};
+  glc_free(p);
+  return a;
+}
+inline std::string lower_ext(const std::string &path) {
+  const size_t slash = path.find_last_of('/'), dot = path.find_last_of('.');
+  if (dot == std::string::npos || (slash != std::string::npos && dot < slash)) return "";
+  std::string e = path.substr(dot + 1);
+  for (char &c : e) c = static_cast<char>(c >= 'A' && c <= 'Z' ? c - 'A' + 'a' : c);
+  return e;
+}
+}  // namespace detail
+// load_audio_file_lossless — src/audio.rs:19-36
+inline LoadedAudio load_audio_file_lossless(const std::string &path) {
+  const std::string ext = detail::lower_ext(path);
+  if (ext.empty()) throw Error(GLC_EINVAL, "No file extension");
+  float *p = nullptr;
+  uint64_t n = 0;
+  uint32_t sr = 0;
+  uint16_t ch = 0;
+  if (ext == "wav") detail::check(glc_wav_load(path.c_str(), &p, &n, &sr, &ch));
+  else if (ext == "flac") detail::check(glc_flac_load(path.c_str(), &p, &n, &sr, &ch));
+  else throw Error(GLC_EINVAL, "Unsupported file format: " + ext);
+  return detail::take(p, n, sr, ch);
+}
+// export_to_wav — src/audio.rs:100-132
+inline void export_to_wav(const std::string &path, const std::vector<float> &s, uint32_t sample_rate, uint16_t channels) {
+  detail::check(glc_wav_save16(path.c_str(), s.data(), s.size(), sample_rate, channels));
+}
+// encode_flac_with_level / encode_flac — src/flac.rs:947-1063
+inline std::vector<uint8_t> encode_flac_with_level(const std::vector<float> &s, uint32_t sample_rate, uint16_t channels,
+                                                   uint8_t compression_level) {
+  uint8_t *p = nullptr;
+  uint64_t n = 0;
+  detail::check(glc_flac_encode(s.data(), s.size(), sample_rate, channels, compression_level, &p, &n));
+  std::vector<uint8_t> out(p, p + n);
+  glc_free(p);
+  return out;
+}
+inline std::vector<uint8_t> encode_flac(const std::vector<float> &s, uint32_t sample_rate, uint16_t channels) {
+  return encode_flac_with_level(s, sample_rate, channels, 5);
+}
+// export_to_flac_with_level / export_to_flac — src/flac.rs:1066-1087, src/audio.rs:87-96
+inline void export_to_flac_with_level(const std::string &path, const std::vector<float> &s, uint32_t sample_rate,
+                                      uint16_t channels, uint8_t compression_level) {
+  detail::check(glc_flac_save(path.c_str(), s.data(), s.size(), sample_rate, channels, compression_level));
+}
+inline void export_to_flac(const std::string &path, const std::vector<float> &s, uint32_t sample_rate, uint16_t channels) {
+  export_to_flac_with_level(path, s, sample_rate, channels, 5);
+}
+
 }  // namespace glc

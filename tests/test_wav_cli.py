@@ -115,7 +115,8 @@ def test_cli_encode_decode_matches_oracle(tmp_path):
     # error paths: a failed file does not stop the others, exit code 1 (src/main.rs:546-581)
     r = subprocess.run([CLI, str(tmp_path / "nope.wav"), str(wav)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "Saved" in r.stdout
-    assert subprocess.run([CLI, "-d", str(tmp_path / "song.glc")], capture_output=True).returncode == 2
+    r = subprocess.run([CLI, "-d", str(tmp_path / "nope.glc"), str(wav)], capture_output=True, text=True)
+    assert r.returncode == 1 and "File not found" in r.stderr and "Not a .glc file" in r.stderr
 
 
 def test_cpp_mirror_header_compiles_standalone(tmp_path):
