@@ -41,8 +41,11 @@ int main(int argc, char **argv) {
       saw_last = c.is_last;
       ++chunks;
     });
-    if (!saw_last || streamed.size() != whole.size() ||
-        std::memcmp(streamed.data(), whole.data(), whole.size() * sizeof(float)) != 0) {
+    // Decoder::decode is the stream with the first encoder_delay values drained and the rest cut
+    // to original_length (src/codec.rs:755-765)
+    const glc::GaplessInfo gi = loaded.gapless_info();
+    if (!saw_last || streamed.size() < gi.encoder_delay + whole.size() || whole.size() != gi.original_length ||
+        std::memcmp(streamed.data() + gi.encoder_delay, whole.data(), whole.size() * sizeof(float)) != 0) {
       std::fprintf(stderr, "streaming decode differs from decode\n");
       return 1;
     }
