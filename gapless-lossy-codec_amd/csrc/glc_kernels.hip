@@ -13,6 +13,8 @@
 //   K3 k_decide_raw    :496-502 (raw plane) + :505-540 (size estimate, decision)
 //   D1 k_imdct_rows    :626-644 (raw frames), :651-665 (dequant), :377-390 (imdct), :672-675
 //   D2 k_overlap_add   :688-705 (overlap-add + interleave), :722-729 (tail)
+#include <cstdlib>
+
 #include "glc_kernels.h"
 #include "glc_mdct_fwd.hpp"
 
@@ -293,6 +295,150 @@ __global__ __launch_bounds__(256) void k_imdct_rows(DeviceTables tb, DecodeRows 
 }
 
 // ------------------------------------------------------------------------------------------
+// D1, grouped: one workgroup decodes G consecutive rows (the channels of a frame and its
+// neighbours in time) over the UNION of their coefficient indices, so that a table row is read
+// from L2 once for the group instead of once per row - stereo pairs and consecutive frames of
+// tonal material share most of their indices.  Per row the arithmetic is unchanged: its stored
+// non-zeros are applied in ascending k; a row that lacks an index of the union skips it (a
+// wave-uniform branch), which is the same identity the sparse skip already relies on.
+//   LDS: dense coefficients [k][G] (zero = absent), a 1024-bit union map, the compacted union list
+// ------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void k_imdct_group(DeviceTables tb, DecodeRows rows, unsigned row_begin,
+                                                      unsigned M, unsigned ch, float *__restrict__ blocks) {
+  __shared__ __attribute__((aligned(16))) float s_c[kHopI * G];
+  __shared__ unsigned s_mask[kHopI / 32];
+  __shared__ unsigned short s_u[kHopI];
+  __shared__ unsigned s_wsum[4];
+  const int tid = threadIdx.x;
+  const unsigned r0 = blockIdx.x * G;
+
+  for (int i = tid; i < kHopI * G; i += 256) s_c[i] = 0.0f;
+  if (tid < kHopI / 32) s_mask[tid] = 0u;
+  __syncthreads();
+
+  unsigned live = 0;  // rows of the group that take the transform path (uniform)
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const unsigned r = r0 + g;
+    if (r >= M) continue;
+    const unsigned m = row_begin + r;
+    const long long raw_off = rows.row_raw[m];
+    if (raw_off >= 0) {
+      // raw frame: read as if interleaved (Q1), /32767, no window (Q2) - src/codec.rs:629-640
+      float *out = blocks + static_cast<size_t>(r) * kFrameI;
+      const unsigned c = m % ch;
+      const unsigned long long raw_len = rows.row_raw_len[m];
+      const short *raw = rows.raw_pool + raw_off;
+      for (int i = tid; i < kFrameI; i += 256) {
+        const unsigned long long si = static_cast<unsigned long long>(i) * ch + c;
+        float v = 0.0f;
+        if (si < raw_len) v = static_cast<float>(raw[si]) / 32767.0f;
+        out[i] = v;
+      }
+      continue;
+    }
+    live |= 1u << g;
+    const unsigned long long p0 = rows.row_begin[m];
+    const unsigned n = min(rows.row_cnt[m], static_cast<unsigned>(kHopI));  // canonical lists hold <= 1024
+    const float scale = fmaxf(rows.row_scale[m], 1e-12f);                  // :653
+    for (unsigned j = tid; j < n; j += 256) {
+      const unsigned pr = rows.pairs[p0 + j];
+      const unsigned idx = pr & 0xFFFFu;
+      const short q = static_cast<short>(pr >> 16);
+      if (idx < static_cast<unsigned>(kHopI)) {
+        s_c[idx * G + g] = mul_rn(static_cast<float>(q) / 32768.0f, scale);  // :663
+        atomicOr(&s_mask[idx >> 5], 1u << (idx & 31));
+      }
+    }
+  }
+  __syncthreads();
+
+  // ascending union list: thread t owns bins 4t..4t+3; exclusive scan of the per-thread counts
+  const unsigned nib = (s_mask[tid >> 3] >> ((tid & 7) * 4)) & 0xFu;
+  const unsigned cnt = __popc(nib);
+  unsigned incl = cnt;
+  const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) s_wsum[w] = incl;
+  __syncthreads();
+  unsigned base = 0, n_u = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned v = s_wsum[i];
+    if (i < w) base += v;
+    n_u += v;
+  }
+  {
+    unsigned pos = base + incl - cnt;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (nib & (1u << b)) s_u[pos++] = static_cast<unsigned short>(tid * 4 + b);
+  }
+  __syncthreads();
+  if (!live) return;
+
+  // packed f32 lanes (v_pk_mul_f32 / v_pk_add_f32: separately rounded, two outputs per issue slot)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x2 acc[G][4];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) acc[g][h] = f32x2{0.f, 0.f};
+  const float *T = tb.cos + tid * 4;
+  f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+  unsigned k = 0;
+  if (n_u) {
+    k = s_u[0];
+    const float *trow = T + static_cast<size_t>(k) * kFrameI;
+    t0 = *reinterpret_cast<const f32x4 *>(trow);
+    t1 = *reinterpret_cast<const f32x4 *>(trow + 1024);
+  }
+#pragma unroll 2
+  for (unsigned j = 0; j < n_u; ++j) {
+    // the next table row is in flight while this one is applied (the last step re-reads its own)
+    const unsigned kn = s_u[j + 1 < n_u ? j + 1 : j];
+    const float *nrow = T + static_cast<size_t>(kn) * kFrameI;
+    const f32x4 n0 = *reinterpret_cast<const f32x4 *>(nrow);
+    const f32x4 n1 = *reinterpret_cast<const f32x4 *>(nrow + 1024);
+    float cg[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) cg[g] = s_c[k * G + g];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float cv = cg[g];
+      if (cv != 0.0f) {  // same value in every lane: the branch is wave-uniform
+        const f32x2 c2 = {cv, cv};
+        acc[g][0] = acc[g][0] + c2 * t0.xy;
+        acc[g][1] = acc[g][1] + c2 * t0.zw;
+        acc[g][2] = acc[g][2] + c2 * t1.xy;
+        acc[g][3] = acc[g][3] + c2 * t1.zw;
+      }
+    }
+    t0 = n0, t1 = n1, k = kn;
+  }
+  const float4 w0 = *reinterpret_cast<const float4 *>(tb.window + tid * 4);
+  const float4 w1 = *reinterpret_cast<const float4 *>(tb.window + 1024 + tid * 4);
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    if (!(live & (1u << g))) continue;
+    float *out = blocks + static_cast<size_t>(r0 + g) * kFrameI;
+    float4 o0, o1;  // out[i] = s*norm (:388) then *= window[i] (:674)
+    o0.x = mul_rn(mul_rn(acc[g][0].x, tb.norm), w0.x); o0.y = mul_rn(mul_rn(acc[g][0].y, tb.norm), w0.y);
+    o0.z = mul_rn(mul_rn(acc[g][1].x, tb.norm), w0.z); o0.w = mul_rn(mul_rn(acc[g][1].y, tb.norm), w0.w);
+    o1.x = mul_rn(mul_rn(acc[g][2].x, tb.norm), w1.x); o1.y = mul_rn(mul_rn(acc[g][2].y, tb.norm), w1.y);
+    o1.z = mul_rn(mul_rn(acc[g][3].x, tb.norm), w1.z); o1.w = mul_rn(mul_rn(acc[g][3].y, tb.norm), w1.w);
+    *reinterpret_cast<float4 *>(out + tid * 4) = o0;
+    *reinterpret_cast<float4 *>(out + 1024 + tid * 4) = o1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // D2: overlap-add + interleave.  blocks holds frames [blk_frame0, ...) as [frame][ch][2048];
 // hop h = second half of frame h-1 (+0.0 before the first frame) + first half of frame h; the
 // hop after the last frame is the bare overlap tail (no add, src/codec.rs:722-729).
@@ -505,7 +651,16 @@ hipError_t launch_pack_rows(const uint8_t *records, uint32_t M, uint32_t ch, con
 hipError_t launch_imdct_rows(const DeviceTables &t, const DecodeRows &rows, uint32_t row_begin,
                              uint32_t M, uint32_t ch, float *blocks, hipStream_t s) {
   if (M == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_imdct_rows, dim3(M), dim3(256), 0, s, t, rows, row_begin, M, ch, blocks);
+  static const int group = [] {  // tuning knob: rows per workgroup (0 = the one-row kernel)
+    const char *e = std::getenv("GLC_D1_GROUP");
+    return e ? std::atoi(e) : 4;
+  }();
+  switch (group) {
+    case 0: hipLaunchKernelGGL(k_imdct_rows, dim3(M), dim3(256), 0, s, t, rows, row_begin, M, ch, blocks); break;
+    case 2: hipLaunchKernelGGL(k_imdct_group<2>, dim3((M + 1) / 2), dim3(256), 0, s, t, rows, row_begin, M, ch, blocks); break;
+    case 8: hipLaunchKernelGGL(k_imdct_group<8>, dim3((M + 7) / 8), dim3(256), 0, s, t, rows, row_begin, M, ch, blocks); break;
+    default: hipLaunchKernelGGL(k_imdct_group<4>, dim3((M + 3) / 4), dim3(256), 0, s, t, rows, row_begin, M, ch, blocks); break;
+  }
   return hipGetLastError();
 }
 
