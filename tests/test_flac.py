@@ -399,3 +399,45 @@ def test_cli_decodes_to_flac_by_default_and_encodes_flac_input(tmp_path):
         assert (tmp_path / "song.flac").read_bytes() == F.encode_flac_with_level(dref, sr, ch, level)
     r = subprocess.run([CLI, "-d", str(tmp_path / "song.glc"), "--flac-level", "9"], capture_output=True, text=True)
     assert r.returncode == 1 and "FLAC level must be 0-8" in r.stderr
+
+
+# ---------------------------------------------------------------- the reference's tests/test_export.rs
+def _export_roundtrip(tmp_path, clips, sr, ch, ext):
+    """tests/test_export.rs:14-165: encode -> decode -> export (FLAC with the flac-export feature,
+    WAV without) -> load_audio_file_lossless; plus the bytes against the oracle."""
+    from oracle import oracle as O
+    enc, dec = glc_amd.Encoder(sr), glc_amd.Decoder(ch, sr)
+    decoded, want = [], []
+    for x in clips:
+        decoded.append(dec.decode(enc.encode(x, ch)))
+        want.append(O.decode(O.encode(x, sr, ch).glc)[0])
+    enc.close(); dec.close()
+    allp, allw = np.concatenate(decoded), np.concatenate(want)
+    assert np.array_equal(allp.view(np.uint32), allw.view(np.uint32))
+    path = tmp_path / f"test_export.{ext}"
+    (glc_amd.export_to_flac if ext == "flac" else glc_amd.export_to_wav)(path, allp, sr, ch)
+    assert path.exists()
+    loaded, rate, nch = glc_amd.load_audio_file_lossless(path)
+    assert rate == sr and nch == ch and loaded.size == allp.size
+    assert np.array_equal(loaded, F.to_i16(allw).astype(np.float32) / np.float32(32768.0))
+    if ext == "flac":
+        assert path.read_bytes() == F.encode_flac_with_level(allw, sr, ch, 5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ext", ["flac", "wav"])
+def test_export_basic(tmp_path, ext):
+    _export_roundtrip(tmp_path, [gen_tone("sine", 440.0, 44100, 2, 2.0)], 44100, 2, ext)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ext", ["flac", "wav"])
+def test_export_mono(tmp_path, ext):
+    _export_roundtrip(tmp_path, [gen_tone("sine", 1000.0, 48000, 1, 1.5)], 48000, 1, ext)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ext", ["flac", "wav"])
+def test_export_gapless_playlist(tmp_path, ext):
+    clips = [gen_tone("sine", f, 44100, 2, 1.0) for f in (440.0, 880.0, 1320.0)]
+    _export_roundtrip(tmp_path, clips, 44100, 2, ext)
