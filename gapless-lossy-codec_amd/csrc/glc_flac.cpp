@@ -465,6 +465,12 @@ struct BitIn {
   }
 };
 
+// Two's-complement wrap-around arithmetic: a damaged stream can make the predictors run away, and
+// that must stay defined behaviour (the frame's CRC-16 rejects it afterwards).
+inline int64_t wadd(int64_t a, int64_t b) { return static_cast<int64_t>(static_cast<uint64_t>(a) + static_cast<uint64_t>(b)); }
+inline int64_t wsub(int64_t a, int64_t b) { return static_cast<int64_t>(static_cast<uint64_t>(a) - static_cast<uint64_t>(b)); }
+inline int64_t wmul(int64_t a, int64_t b) { return static_cast<int64_t>(static_cast<uint64_t>(a) * static_cast<uint64_t>(b)); }
+
 const char *read_residual(BitIn &r, int64_t *s, size_t block, size_t order) {
   const unsigned method = static_cast<unsigned>(r.get(2));
   if (method > 1) return "reserved residual coding method";
@@ -514,12 +520,12 @@ const char *read_subframe(BitIn &r, int64_t *s, size_t block, unsigned bps) {
       int64_t pred = 0;
       switch (order) {
         case 1: pred = s[i - 1]; break;
-        case 2: pred = 2 * s[i - 1] - s[i - 2]; break;
-        case 3: pred = 3 * s[i - 1] - 3 * s[i - 2] + s[i - 3]; break;
-        case 4: pred = 4 * s[i - 1] - 6 * s[i - 2] + 4 * s[i - 3] - s[i - 4]; break;
+        case 2: pred = wsub(wmul(2, s[i - 1]), s[i - 2]); break;
+        case 3: pred = wadd(wsub(wmul(3, s[i - 1]), wmul(3, s[i - 2])), s[i - 3]); break;
+        case 4: pred = wsub(wadd(wsub(wmul(4, s[i - 1]), wmul(6, s[i - 2])), wmul(4, s[i - 3])), s[i - 4]); break;
         default: break;
       }
-      s[i] += pred;
+      s[i] = wadd(s[i], pred);
     }
   } else if (type >= 32) {
     const size_t order = (type & 31) + 1;
@@ -534,8 +540,8 @@ const char *read_subframe(BitIn &r, int64_t *s, size_t block, unsigned bps) {
     if (const char *e = read_residual(r, s, block, order)) return e;
     for (size_t i = order; i < block; ++i) {
       int64_t acc = 0;
-      for (size_t j = 0; j < order; ++j) acc += coef[j] * s[i - 1 - j];
-      s[i] += acc >> shift;
+      for (size_t j = 0; j < order; ++j) acc = wadd(acc, wmul(coef[j], s[i - 1 - j]));
+      s[i] = wadd(s[i], acc >> shift);
     }
   } else {
     return "reserved subframe type";
@@ -591,7 +597,9 @@ int flac_decode(const Span f, std::vector<float> &out, uint32_t &sample_rate, ui
   // `(1 << (bits_per_sample - 1)) as f32`, audio.rs:72
   const float scale = static_cast<float>(1ull << (info_bps - 1));
   out.clear();
-  if (info_total) out.reserve(static_cast<size_t>(info_total * info_ch));
+  // STREAMINFO's sample count is a hint from the file, not a promise: reserve no more than the
+  // remaining bytes could plausibly hold (the vector still grows if constant frames beat that)
+  if (info_total) out.reserve(static_cast<size_t>(std::min<uint64_t>(info_total * info_ch, (f.size() - pos) * 8ull)));
   std::vector<int64_t> plane;
   while (pos < f.size()) {
     BitIn r{f.data() + pos, f.size() - pos};
@@ -641,14 +649,14 @@ int flac_decode(const Span f, std::vector<float> &out, uint32_t &sample_rate, ui
     if (crc16(f.data() + pos, body) != r.get(16) || r.bad) return fail("frame CRC-16 mismatch");
     int64_t *a = plane.data(), *b = plane.data() + block;
     if (ccode == 8) {
-      for (size_t i = 0; i < block; ++i) b[i] = a[i] - b[i];
+      for (size_t i = 0; i < block; ++i) b[i] = wsub(a[i], b[i]);
     } else if (ccode == 9) {
-      for (size_t i = 0; i < block; ++i) a[i] = a[i] + b[i];
+      for (size_t i = 0; i < block; ++i) a[i] = wadd(a[i], b[i]);
     } else if (ccode == 10) {
       for (size_t i = 0; i < block; ++i) {
-        const int64_t mid = (a[i] * 2) | (b[i] & 1), sd = b[i];
-        a[i] = (mid + sd) >> 1;
-        b[i] = (mid - sd) >> 1;
+        const int64_t mid = wmul(a[i], 2) | (b[i] & 1), sd = b[i];
+        a[i] = wadd(mid, sd) >> 1;
+        b[i] = wsub(mid, sd) >> 1;
       }
     }
     const size_t base = out.size();
@@ -732,7 +740,7 @@ int glc_flac_decode(const uint8_t *buf, uint64_t len, float **samples, uint64_t 
     if (rc != GLC_OK) return rc;
     float *o = static_cast<float *>(std::malloc((pcm.size() ? pcm.size() : 1) * sizeof(float)));
     if (!o) return GLC_ENOMEM;
-    std::memcpy(o, pcm.data(), pcm.size() * sizeof(float));
+    if (!pcm.empty()) std::memcpy(o, pcm.data(), pcm.size() * sizeof(float));
     *samples = o;
     *n_samples = pcm.size();
     return GLC_OK;

@@ -193,3 +193,20 @@ def test_container_fuzz_never_crashes():
         assert len(again) <= len(data)
 
     run()
+
+
+def test_host_parsers_under_address_and_ub_sanitizers(tmp_path):
+    """tools/host_fuzz.cpp: the container, WAV and FLAC readers / writers built with
+    -fsanitize=address,undefined (host code only; GPU sanitizers do not exist on the pool) and
+    driven with mutated files plus their round-trip properties for a few seconds."""
+    import subprocess
+    csrc = os.path.join(ROOT, "gapless-lossy-codec_amd", "csrc")
+    exe = tmp_path / "host_fuzz"
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "host_fuzz.cpp")]
+    cmd += [os.path.join(csrc, f) for f in ("glc_frames.cpp", "glc_tables.cpp", "glc_wav.cpp", "glc_flac.cpp")]
+    cmd += ["-lpthread", "-o", str(exe)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe), "6", str(tmp_path), "0x5eed"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "rounds clean" in r.stdout, r.stderr[-3000:]
