@@ -265,8 +265,10 @@ class Decoder(_Ctx):
         if sender is not None:
             sender(kind, value)
 
-    def decode(self, encoded: EncodedAudio, progress_sender=None) -> np.ndarray:
-        """Decoder::decode — src/codec.rs:744-768 (overlap-add, gapless trim)."""
+    def decode(self, encoded: EncodedAudio, progress_sender=None, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """Decoder::decode — src/codec.rs:744-768 (overlap-add, gapless trim).  `out` (optional, not
+        in the reference): a float32 array of at least total_samples to decode into, for callers
+        that reuse a buffer - pages that were touched before take the D2H copies much faster."""
         if progress_sender is not None:  # the reference decodes through decode_streaming (:747)
             chunks = [c.samples for c in self.decode_streaming(encoded, progress_sender)]
             allv = np.concatenate(chunks) if chunks else np.empty(0, np.float32)
@@ -275,7 +277,10 @@ class Decoder(_Ctx):
                 allv = allv[g.encoder_delay:]
             return allv[:g.original_length].copy()
         n = lib.glc_decoded_len(encoded._h)
-        out = np.empty(n, np.float32)
+        if out is None:
+            out = np.empty(n, np.float32)
+        elif out.dtype != np.float32 or not out.flags.c_contiguous or out.size < n:
+            raise GlcError(GLC_EINVAL, "out must be a C-contiguous float32 array of at least total_samples")
         got = C.c_uint64()
         check(lib.glc_decode(self._h, encoded._h, out.ctypes.data_as(C.c_void_p), n, C.byref(got)),
               self._h)

@@ -12,6 +12,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <cstdlib>
 #include <vector>
 
 #include "glc_common.h"
@@ -55,6 +56,8 @@ struct glc_ctx {
   hipStream_t stream = nullptr;      // stream in use
   hipStream_t own_stream = nullptr;  // the context's private stream
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;  // glc_ctx_timer_*
+  hipStream_t copy_stream = nullptr;  // glc_encode: uploads run ahead of the kernels on this one
+  hipEvent_t ev_copy = nullptr;
   glc::HostTables host;
   glc::DeviceTables dev{};
   DevBuf tables;     // all constant tables in one allocation
@@ -220,6 +223,8 @@ void glc_ctx_destroy(glc_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
   if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+  if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   ctx->tables.release();
   ctx->coef.release();
@@ -464,10 +469,38 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
   const uint64_t t_count = (n_samples + ch - 1) / ch;
   GLC_HIP(ctx, ctx->pcm.reserve(static_cast<size_t>(t_count) * ch * sizeof(float)));
   GLC_HIP(ctx, ctx->records.reserve(static_cast<size_t>(plan.n_frames) * rec));
-  GLC_HIP(ctx, hipMemcpyAsync(ctx->pcm.p, pcm, n_samples * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-  int rc = glc_encode_range_device(ctx, static_cast<const float *>(ctx->pcm.p), 0, t_count, n_samples,
-                                   channels, 0, plan.n_frames, ctx->records.p, nullptr);
-  if (rc != GLC_OK) return rc;
+  // Upload and transform in rounds of kEncodeChunkFrames: round i's samples go up on the copy
+  // stream while round i-1's kernels run, so the call costs max(PCIe, kernels) instead of their sum.
+  if (!ctx->copy_stream) GLC_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  if (!ctx->ev_copy) GLC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_copy, hipEventDisableTiming));
+  GLC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // earlier work may still read the staging buffer
+  float *d_pcm = static_cast<float *>(ctx->pcm.p);
+  uint64_t copied = 0;  // interleaved samples already on the device
+  int rc = GLC_OK;
+  for (uint64_t f = 0; f < plan.n_frames && rc == GLC_OK; f += kEncodeChunkFrames) {
+    const uint64_t nf = std::min<uint64_t>(kEncodeChunkFrames, plan.n_frames - f);
+    // frames [f, f+nf) read per-channel samples below 1024*(f+nf-1) - 512 + 2048
+    const uint64_t hi_t = std::min<uint64_t>(t_count, (f + nf - 1) * glc::kHop + glc::kFrame - glc::kHop / 2);
+    const uint64_t hi = std::min<uint64_t>(n_samples, hi_t * ch);
+    hipError_t e = hipSuccess;
+    if (hi > copied) {
+      e = hipMemcpyAsync(d_pcm + copied, pcm + copied, (hi - copied) * sizeof(float), hipMemcpyHostToDevice,
+                         ctx->copy_stream);
+      copied = hi;
+    }
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev_copy, ctx->copy_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_copy, 0);
+    if (e != hipSuccess) {
+      rc = hip_fail(ctx, e, "glc_encode: upload");
+      break;
+    }
+    rc = glc_encode_range_device(ctx, d_pcm, 0, t_count, n_samples, channels, f, f + nf,
+                                 static_cast<uint8_t *>(ctx->records.p) + f * rec, nullptr);
+  }
+  if (rc != GLC_OK) {
+    (void)hipStreamSynchronize(ctx->copy_stream);
+    return rc;
+  }
   // compact on the device; only pairs / scales / raw planes cross PCIe
   return glc_frames_from_device_records(ctx, ctx->records.p, plan.n_frames, n_samples, channels, out);
 }

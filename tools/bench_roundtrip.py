@@ -17,11 +17,12 @@ seg = gen_chord(sr, ch, 480000)
 x = np.tile(seg.reshape(-1, ch), (60, 1)).reshape(-1)
 enc = glc_amd.Encoder(sr)
 dec = glc_amd.Decoder(ch, sr)
-for rep in range(3):
+reuse = np.zeros(x.size, np.float32)  # a destination whose pages exist already
+for rep in range(6):
     t0 = time.perf_counter()
     ea = enc.encode(x, ch)
     t1 = time.perf_counter()
-    out = dec.decode(ea)
+    out = dec.decode(ea) if rep < 3 else dec.decode(ea, out=reuse)   # fresh pages vs reused buffer
     t2 = time.perf_counter()
     data = ea.to_bytes()
     t3 = time.perf_counter()
