@@ -630,14 +630,21 @@ inline hipError_t launch_sched(const DeviceTables &t, const PcmView &pcm, uint64
 // `s_waitcnt vmcnt(1)` per stage waits for the PCM loads and the table DMA of the NEXT stage while
 // leaving the DMA of the stage after it in flight.  Same arithmetic, same order.
 // ------------------------------------------------------------------------------------------
-template <int MINW, int ABL = 0>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
+template <int MINW, int ABL = 0, int BM = 128>
+__global__ __launch_bounds__(4 * BM) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
 void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigned M, float *__restrict__ coef) {
-  constexpr int BM = 128, BN = 128, BK = 16, TM = 4, RING = 3;
+  // BM = 128: 512 threads, 2 workgroups per CU (56 KiB LDS each).  BM = 64: 256 threads, window
+  // values by scalar loads instead of LDS (36 KiB), 4 workgroups per CU - each SIMD then holds one
+  // wave of four DIFFERENT workgroups, whose barrier waits do not coincide.
+  constexpr int BN = 128, BK = 16, TM = 4, RING = 3;
+  constexpr int kThreads = 4 * BM, kWaves = kThreads / 64;
   constexpr int kAPer = 4, kAStride = 4;
+  constexpr bool kWinLds = BM == 128;
+  constexpr int kDma = (BK * BN * 4) / (kThreads * 16);  // table-DMA instructions per thread and stage
+  static_assert(BM == 128 || BM == 64, "tile heights with a hand-written schedule");
   __shared__ __attribute__((aligned(16))) float As[RING][BK * BM];
   __shared__ __attribute__((aligned(16))) float Bs[RING][BK * BN];
-  __shared__ __attribute__((aligned(16))) float Ws[kFrameI];
+  __shared__ __attribute__((aligned(16))) float Ws[kWinLds ? kFrameI : 4];
 
   const int tid = threadIdx.x;
   const unsigned g = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD-aware tile map
@@ -649,7 +656,8 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
 
-  for (int i = tid; i < kFrameI; i += 512) Ws[i] = tb.window[i];
+  if constexpr (kWinLds)
+    for (int i = tid; i < kFrameI; i += kThreads) Ws[i] = tb.window[i];
 
   const long long ch = pcm.ch;
   const long long f0 = frame_begin + m0 / pcm.ch;
@@ -665,7 +673,8 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
       const_cast<float *>(pcm.p + e_base), 0, static_cast<int>(e_cnt * 4), 0x00020000);
 
   const int a_r = tid % BM;
-  const int a_i = tid / BM;  // 0..3: i = a_i + 4 j
+  const int a_i = tid / BM;  // 0..3: i = a_i + 4 j  (the same for every lane of a wave)
+  const int a_i_s = __builtin_amdgcn_readfirstlane(a_i);
   const unsigned a_row = m0 + a_r;
   unsigned a_off = 0x80000000u;
   if (a_row < M) {
@@ -676,7 +685,8 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
   }
   const unsigned a_step = static_cast<unsigned>(kAStride * ch * 4);
   const unsigned i_bytes = static_cast<unsigned>(ch * 4);
-  // table DMA: wave w copies rows 2w, 2w+1 of the stage's 16 x 128 tile (1 KiB, lane-linear)
+  // table DMA: instruction d of wave w copies rows 2(d*kWaves + w), +1 of the stage's 16 x 128
+  // tile (1 KiB, lane-linear)
   const float *b_src = tb.cos_t + n0 + static_cast<size_t>(2 * wave + (lane >> 5)) * kHopI + (lane & 31) * 4;
 
   float a_raw[kAPer];
@@ -692,14 +702,49 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
         : "memory");
   };
   auto issue_b = [&](int i0, int slot) {
-    __builtin_amdgcn_global_load_lds(b_src + static_cast<size_t>(i0) * kHopI, &Bs[slot][2 * wave * BN], 16, 0, 0);
+#pragma unroll
+    for (int d = 0; d < kDma; ++d)
+      __builtin_amdgcn_global_load_lds(b_src + static_cast<size_t>(i0 + 2 * d * kWaves) * kHopI,
+                                       &Bs[slot][2 * (d * kWaves + wave) * BN], 16, 0, 0);
+  };
+  // window values of a stage: from LDS, or (BM = 64) four wave-uniform scalar loads.  hipcc would
+  // use vector loads here (it cannot prove the table unclobbered across the asm blocks) and then
+  // wait for vmcnt(0), DMA included, so the s_loads are written by hand; `pin_w` after an
+  // lgkmcnt(0) wait is what makes their results visible to the compiler-scheduled consumers.
+  float w_next[kAPer] = {0.f, 0.f, 0.f, 0.f}, w_far[kAPer] = {0.f, 0.f, 0.f, 0.f};
+  auto load_w = [&](int i0) {
+    if constexpr (!kWinLds) {
+      const float *wp = tb.window + i0 + a_i_s;
+      asm volatile(
+          "s_load_dword %0, %4, 0x0\n\t"
+          "s_load_dword %1, %4, 0x10\n\t"
+          "s_load_dword %2, %4, 0x20\n\t"
+          "s_load_dword %3, %4, 0x30"
+          : "=&s"(w_far[0]), "=&s"(w_far[1]), "=&s"(w_far[2]), "=&s"(w_far[3])
+          : "s"(wp)
+          : "memory");
+    }
+  };
+  auto pin_w = [&]() {  // call only behind an lgkmcnt(0) wait
+    if constexpr (!kWinLds) {
+      asm volatile("" : "+s"(w_far[0]), "+s"(w_far[1]), "+s"(w_far[2]), "+s"(w_far[3]));
+#pragma unroll
+      for (int j = 0; j < kAPer; ++j) w_next[j] = w_far[j];
+    }
   };
   auto store_a = [&](int i0, int slot) {
 #pragma unroll
     for (int j = 0; j < kAPer; ++j) {
       const int ii = a_i + kAStride * j;
-      As[slot][ii * BM + a_r] = mul_rn(a_raw[j], Ws[i0 + ii]);  // block[i] = slice[i]*window[i], :480
+      const float wv = kWinLds ? Ws[i0 + ii] : w_next[j];
+      As[slot][ii * BM + a_r] = mul_rn(a_raw[j], wv);  // block[i] = slice[i]*window[i], :480
     }
+  };
+  auto wait_all_but_newest_dma = [&]() {
+    if constexpr (kDma == 1)
+      asm volatile("s_waitcnt vmcnt(1)" : "+v"(a_raw[0]), "+v"(a_raw[1]), "+v"(a_raw[2]), "+v"(a_raw[3])::"memory");
+    else
+      asm volatile("s_waitcnt vmcnt(2)" : "+v"(a_raw[0]), "+v"(a_raw[1]), "+v"(a_raw[2]), "+v"(a_raw[3])::"memory");
   };
 
   f32x2 acc[TM][4];
@@ -713,10 +758,15 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
   __syncthreads();  // Ws
   issue_a(0);
   issue_b(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a_raw[0]), "+v"(a_raw[1]), "+v"(a_raw[2]), "+v"(a_raw[3])::"memory");
+  load_w(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(a_raw[0]), "+v"(a_raw[1]), "+v"(a_raw[2]), "+v"(a_raw[3])::"memory");
+  pin_w();
   store_a(0, 0);
   issue_a(BK);
   issue_b(BK, 1);
+  load_w(BK);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  pin_w();
   __syncthreads();
 
   const unsigned a_lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(&As[0][ty * 4]));
@@ -730,8 +780,10 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
     const unsigned a_addr = a_lds0 + slot * (BK * BM * 4);
     const unsigned b_addr = b_lds0 + slot * (BK * BN * 4);
     Operands X, Y;
+    if (ABL == 0 && s > 0) load_w(((s + 1) & (kStages - 1)) * BK);  // s == 0: loaded by the prologue
     lds_fetch4<BM, BN>(X, a_addr, b_addr, 0);
-    lds_wait4(X);
+    lds_wait4(X);  // lgkmcnt(0): the scalar loads above are back as well
+    if (ABL == 0 && s > 0) pin_w();
 #pragma unroll
     for (int ii = 0; ii < BK; ii += 2) {
       step4<BM, BN, true>(acc, X, Y, a_addr, b_addr, ii + 1);
@@ -739,9 +791,9 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
       else step4<BM, BN, false>(acc, Y, X, a_addr, b_addr, 0);
     }
     if (ABL == 0) {
-      // everything but the youngest vector-memory op (the DMA of stage s+2) has landed: the PCM
+      // everything but the youngest vector-memory ops (the DMA of stage s+2) has landed: the PCM
       // registers of stage s+1 and, older still, the table DMA of stage s+1
-      asm volatile("s_waitcnt vmcnt(1)" : "+v"(a_raw[0]), "+v"(a_raw[1]), "+v"(a_raw[2]), "+v"(a_raw[3])::"memory");
+      wait_all_but_newest_dma();
       store_a(((s + 1) & (kStages - 1)) * BK, (s + 1) % 3);
       issue_a(((s + 2) & (kStages - 1)) * BK);
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's ds_writes of stage s+1 have landed
@@ -765,12 +817,12 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
   }
 }
 
-template <int MINW, int ABL = 0>
+template <int MINW, int ABL = 0, int BM = 128>
 inline hipError_t launch_dma(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M,
                              float *coef, hipStream_t s) {
   if (M == 0) return hipSuccess;
-  const unsigned m_tiles = (M + 127) / 128;
-  hipLaunchKernelGGL((k_mdct_fwd_dma<MINW, ABL>), dim3(m_tiles * 8), dim3(512), 0, s, t, pcm,
+  const unsigned m_tiles = (M + BM - 1) / BM;
+  hipLaunchKernelGGL((k_mdct_fwd_dma<MINW, ABL, BM>), dim3(m_tiles * 8), dim3(4 * BM), 0, s, t, pcm,
                      static_cast<long long>(frame_begin), M, coef);
   return hipGetLastError();
 }
