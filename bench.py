@@ -271,7 +271,7 @@ def main():
         sec = min(O.time_encode_frames(pcm_host, SR, CH, 0, nfr, n_threads=cores) for _ in range(2))
         cpu = {"value": round(nfr * HOP * CH / sec / 1e6, 3), "unit": "Msamples/s", "cores": cores,
                "kind": "port",
-               "sample": f"all {nfr} frames of the same 48 kHz stereo batch, one pass, {cores} threads "
+               "sample": f"all {nfr} frames of the same 48 kHz stereo batch, best of 2 passes, {cores} threads "
                          f"({sec:.2f} s wall); C restatement of src/codec.rs (no Rust toolchain in the image)"}
 
     traffic = None
