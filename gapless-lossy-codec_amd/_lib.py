@@ -62,6 +62,7 @@ SIGNATURES = {
     "glc_decoded_len": (C.c_uint64, [_vp]),
     "glc_decode": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "glc_decode_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "glc_decode_range_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64]),
     "glc_decode_stream_begin": (C.c_int, [_vp, _vp]),
     "glc_decode_stream_next": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_int)]),

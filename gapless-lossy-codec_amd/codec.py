@@ -296,6 +296,11 @@ class Decoder(_Ctx):
               self._h)
         return start.value, n.value
 
+    def decode_range_device(self, encoded: EncodedAudio, hop_begin: int, hop_end: int, d_out: int, cap: int) -> None:
+        """One shard of the decode: hops [hop_begin, hop_end) of the un-trimmed stream into device
+        memory at address d_out (glc_decode_range_device).  Queued, not synchronised."""
+        check(lib.glc_decode_range_device(self._h, encoded._h, hop_begin, hop_end, C.c_void_p(d_out), cap), self._h)
+
     def decode_streaming(self, encoded: EncodedAudio, progress_sender=None) -> Iterator[AudioChunk]:
         """Decoder::decode_streaming — src/codec.rs:595-741: yields AudioChunk until is_last."""
         import time as _time

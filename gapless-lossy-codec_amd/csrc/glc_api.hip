@@ -666,6 +666,43 @@ int decode_chunk(glc_ctx *ctx, uint64_t n, bool emit_tail, float *dst, uint64_t 
   return GLC_OK;
 }
 
+// Hops [hop_begin, hop_end) of the un-trimmed stream (hop h = second half of frame h-1 + first
+// half of frame h; hop n_frames is the bare tail) into device memory at d_out, after
+// decode_prepare.  A range that does not start at 0 recomputes frame hop_begin-1 as its halo: the
+// only state the overlap-add carries (src/codec.rs:701-705), which is what lets GPUs decode
+// disjoint hop ranges of one stream independently.
+int decode_hops_prepared(glc_ctx *ctx, uint64_t hop_begin, uint64_t hop_end, float *d_out) {
+  if (hop_end <= hop_begin) return GLC_OK;
+  const uint32_t ch = ctx->dec_ch;
+  const uint64_t nf = ctx->dec_frames;
+  DeviceGuard guard(ctx->device);
+  const uint64_t f_end = std::min(hop_end, nf);  // frames [hop_begin, f_end) are decoded for their own hops
+  const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(kDecodeChunkFrames, f_end > hop_begin ? f_end - hop_begin : 1));
+  const size_t slot = static_cast<size_t>(ch) * glc::kFrame;
+  GLC_HIP(ctx, ctx->blocks.reserve((chunk + 1) * slot * sizeof(float)));
+  float *blocks = static_cast<float *>(ctx->blocks.p);
+  if (hop_begin == 0)
+    GLC_HIP(ctx, hipMemsetAsync(blocks, 0, slot * sizeof(float), ctx->stream));  // overlap = 0.0, :601
+  else
+    GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, static_cast<uint32_t>((hop_begin - 1) * ch), ch, ch,
+                                        blocks, ctx->stream));
+  uint64_t f0 = hop_begin;
+  do {
+    const uint64_t nchunk = f0 < f_end ? std::min(chunk, f_end - f0) : 0;
+    const bool tail = f0 + nchunk == nf && hop_end == nf + 1;  // this round also emits the bare overlap tail
+    if (nchunk)
+      GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, static_cast<uint32_t>(f0 * ch),
+                                          static_cast<uint32_t>(nchunk * ch), ch, blocks + slot, ctx->stream));
+    GLC_HIP(ctx, glc::launch_overlap_add(blocks, static_cast<int64_t>(f0) - 1, nf, ch, f0, f0 + nchunk + (tail ? 1 : 0),
+                                         d_out + (f0 - hop_begin) * glc::kHop * ch, ctx->stream));
+    f0 += nchunk + (tail ? 1 : 0);
+    if (f0 < hop_end)
+      GLC_HIP(ctx, hipMemcpyAsync(blocks, blocks + nchunk * slot, slot * sizeof(float), hipMemcpyDeviceToDevice,
+                                  ctx->stream));
+  } while (f0 < hop_end);
+  return GLC_OK;
+}
+
 }  // namespace
 
 int glc_decode(glc_ctx *ctx, const glc_frames *in, float *pcm_out, uint64_t cap, uint64_t *n_out) {
@@ -714,28 +751,20 @@ int glc_decode_device(glc_ctx *ctx, const glc_frames *in, float *d_all, uint64_t
   if (n_out) *n_out = n;
   int rc = decode_prepare(ctx, in);
   if (rc != GLC_OK) return rc;
-  DeviceGuard guard(ctx->device);
-  const uint64_t nf = in->n_frames;
-  const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(kDecodeChunkFrames, nf));
-  const size_t slot = static_cast<size_t>(ch) * glc::kFrame;
-  GLC_HIP(ctx, ctx->blocks.reserve((chunk + 1) * slot * sizeof(float)));
-  float *blocks = static_cast<float *>(ctx->blocks.p);
-  GLC_HIP(ctx, hipMemsetAsync(blocks, 0, slot * sizeof(float), ctx->stream));  // overlap = 0.0, :601
-  uint64_t f0 = 0;
-  do {
-    const uint64_t nchunk = std::min(chunk, nf - f0);
-    const bool last = f0 + nchunk == nf;
-    if (nchunk)
-      GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, static_cast<uint32_t>(f0 * ch),
-                                          static_cast<uint32_t>(nchunk * ch), ch, blocks + slot, ctx->stream));
-    GLC_HIP(ctx, glc::launch_overlap_add(blocks, static_cast<int64_t>(f0) - 1, nf, ch, f0, f0 + nchunk + (last ? 1 : 0),
-                                         d_all + f0 * glc::kHop * ch, ctx->stream));
-    if (!last)
-      GLC_HIP(ctx, hipMemcpyAsync(blocks, blocks + nchunk * slot, slot * sizeof(float), hipMemcpyDeviceToDevice,
-                                  ctx->stream));
-    f0 += nchunk;
-  } while (f0 < nf);
-  return GLC_OK;
+  return decode_hops_prepared(ctx, 0, in->n_frames + 1, d_all);
+}
+
+int glc_decode_range_device(glc_ctx *ctx, const glc_frames *in, uint64_t hop_begin, uint64_t hop_end,
+                            float *d_out, uint64_t cap) {
+  if (!ctx || !in || !d_out) return fail(ctx, GLC_EINVAL, "glc_decode_range_device: null argument");
+  ctx->stream_open = false;
+  if (hop_begin > hop_end || hop_end > in->n_frames + 1)
+    return fail(ctx, GLC_EINVAL, "glc_decode_range_device: hop range out of bounds");
+  if (cap < (hop_end - hop_begin) * glc::kHop * in->channels)
+    return fail(ctx, GLC_EINVAL, "glc_decode_range_device: output buffer too small");
+  int rc = decode_prepare(ctx, in);
+  if (rc != GLC_OK) return rc;
+  return decode_hops_prepared(ctx, hop_begin, hop_end, d_out);
 }
 
 int glc_decode_stream_begin(glc_ctx *ctx, const glc_frames *in) {

@@ -6,7 +6,8 @@ range [f0_r, f1_r) from the slice of interleaved PCM that range reads — per-ch
 neighbours, supplied at upload time (no device exchange).  Every rank emits fixed-size frame
 records; ONE gather of those records to rank 0 is the only collective (RCCL over xGMI when the
 process group is `nccl`, gloo in the CPU tests).  Rank 0 assembles EncodedAudio from the
-concatenated records with glc_frames_from_records.
+concatenated records with glc_frames_from_records.  Decode shards the same way over hop ranges
+(`hop_ranges`), each rank recomputing one halo frame.
 """
 from __future__ import annotations
 
@@ -39,6 +40,14 @@ def frame_ranges(n_frames: int, world: int) -> List[range]:
         out.append(range(f, f + n))
         f += n
     return out
+
+
+def hop_ranges(n_frames: int, world: int) -> List[range]:
+    """Decode side: the un-trimmed output has n_frames + 1 hops of 1024 samples per channel (the
+    last one is the overlap tail); rank r decodes a contiguous hop range with
+    glc_decode_range_device, which recomputes the one halo frame its overlap-add needs, and the
+    ranks' PCM concatenates in rank order (one gather of PCM, no other exchange)."""
+    return frame_ranges(n_frames + 1, world)
 
 
 def plan_shards(n_frames: int, per_channel: int, world: int) -> List[Shard]:

@@ -161,6 +161,15 @@ int glc_decode(glc_ctx *ctx, const glc_frames *in, float *pcm_out, uint64_t cap,
 int glc_decode_device(glc_ctx *ctx, const glc_frames *in, float *d_all, uint64_t cap_all,
                       uint64_t *start, uint64_t *n_out);
 
+/* One shard of the same decode (multi-GPU): hops [hop_begin, hop_end) of the
+ * un-trimmed stream, hop_end <= n_frames + 1, written to d_out (hop hop_begin at d_out[0], capacity
+ * cap samples).  Hop h is the second half of frame h-1 plus the first half of frame h
+ * (src/codec.rs:688-705), hop n_frames the bare overlap tail (:722-729); a range that does not
+ * start at 0 recomputes frame hop_begin-1 as its halo, so disjoint ranges decoded on different
+ * GPUs concatenate to exactly the whole-stream output.  Queued on the context's stream. */
+int glc_decode_range_device(glc_ctx *ctx, const glc_frames *in, uint64_t hop_begin,
+                            uint64_t hop_end, float *d_out, uint64_t cap);
+
 /* Decoder::decode_streaming src/codec.rs:595-741: un-trimmed output delivered in chunks of at
  * least FRAMES_PER_CHUNK*1024*channels samples (AudioChunk, :81-85).  `begin` decodes on the
  * device; `next` copies the next chunk (returns its size through n_out, sets *is_last on the

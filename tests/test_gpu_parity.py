@@ -444,6 +444,43 @@ def test_device_resident_decode(torch_cuda):
         dec.decode_device(enc, d_all.data_ptr(), d_all.numel() - 1)
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_decode_equals_whole_stream(torch_cuda, world):
+    """SURVEY 8e, decode side: disjoint hop ranges decoded independently (each recomputes one
+    halo frame for the overlap-add) concatenate to the whole-stream output bit for bit - across
+    raw frames, the 4096-frame round boundary, the stream start (+0.0 overlap) and the bare tail."""
+    sr, ch = 48000, 2
+    x = np.concatenate([gen_chord(sr, ch, 4200 * 1024, n_tones=5), gen_noise(sr, ch, 0.2, 4),
+                        gen_chord(sr, ch, 100 * 1024, n_tones=3, seed=9)])
+    enc = glc_amd.Encoder(sr).encode(x, ch)
+    nf = enc.info().n_frames
+    dec = glc_amd.Decoder(ch, sr)
+    whole = torch_cuda.empty((nf + 1) * 1024 * ch, dtype=torch_cuda.float32, device="cuda")
+    dec.decode_device(enc, whole.data_ptr(), whole.numel())
+    dec.synchronize()
+    want = whole.cpu().numpy()
+    parts = []
+    for r in glc_amd.shard.hop_ranges(nf, world):
+        d = torch_cuda.full((max(len(r), 1) * 1024 * ch,), float("nan"), dtype=torch_cuda.float32, device="cuda")
+        torch_cuda.cuda.synchronize()
+        dec.decode_range_device(enc, r.start, r.stop, d.data_ptr(), d.numel())
+        dec.synchronize()
+        parts.append(d.cpu().numpy()[:len(r) * 1024 * ch])
+    got = np.concatenate(parts)
+    assert got.size == want.size and np.array_equal(bits(got), bits(want))
+    # odd cuts: a single hop in the middle, the tail alone, an empty range
+    for a, b in ((nf // 2, nf // 2 + 1), (nf, nf + 1), (7, 7), (4095, 4098), (0, 1)):
+        d = torch_cuda.empty(max(b - a, 1) * 1024 * ch, dtype=torch_cuda.float32, device="cuda")
+        torch_cuda.cuda.synchronize()
+        dec.decode_range_device(enc, a, b, d.data_ptr(), d.numel())
+        dec.synchronize()
+        assert np.array_equal(bits(d.cpu().numpy()[:(b - a) * 1024 * ch]), bits(want[a * 1024 * ch:b * 1024 * ch]))
+    with pytest.raises(glc_amd.GlcError):
+        dec.decode_range_device(enc, 0, nf + 2, whole.data_ptr(), whole.numel())
+    with pytest.raises(glc_amd.GlcError):
+        dec.decode_range_device(enc, 0, 10, whole.data_ptr(), 10 * 1024 * ch - 1)
+
+
 def test_progress_messages(torch_cuda):
     """Progress (src/codec.rs:71-79) as the streaming decoder sends it (:609, :713, :736)."""
     sr, ch = 44100, 1

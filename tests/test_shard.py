@@ -87,3 +87,14 @@ def test_sharded_encode_gathers_to_identical_bytes(world):
         p.join(180)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_hop_ranges_cover_the_untrimmed_stream():
+    """Decode shards: n_frames + 1 hops, contiguous, balanced, in rank order."""
+    from glc_amd import shard
+    for nf in (0, 1, 5, 86, 4096, 28125):
+        for world in (1, 2, 3, 8):
+            rs = shard.hop_ranges(nf, world)
+            assert len(rs) == world and rs[0].start == 0 and rs[-1].stop == nf + 1
+            assert all(a.stop == b.start for a, b in zip(rs, rs[1:]))
+            assert max(map(len, rs)) - min(map(len, rs)) <= 1
