@@ -441,3 +441,27 @@ def test_export_mono(tmp_path, ext):
 def test_export_gapless_playlist(tmp_path, ext):
     clips = [gen_tone("sine", f, 44100, 2, 1.0) for f in (440.0, 880.0, 1320.0)]
     _export_roundtrip(tmp_path, clips, 44100, 2, ext)
+
+
+# ---------------------------------------------------------------- committed fixtures (tests/golden/make_golden_flac.py)
+def test_flac_golden_fixtures():
+    """The frozen oracle bytes: the product reproduces them, the oracle still does, and the
+    product's decoder reads them back to the generating signal."""
+    import json
+    import importlib.util
+    gdir = os.path.join(ROOT, "tests", "golden")
+    spec = importlib.util.spec_from_file_location("make_golden_flac", os.path.join(gdir, "make_golden_flac.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    cases = json.load(open(os.path.join(gdir, "flac_golden.json")))
+    assert len(cases) == len(mk.CASES)
+    for c in cases:
+        x = mk.signal(c["signal"])
+        assert hashlib.sha256(x.tobytes()).hexdigest() == c["input_sha256"]
+        want = open(os.path.join(gdir, c["file"]), "rb").read()
+        assert len(want) == c["length"] and hashlib.sha256(want).hexdigest() == c["sha256"]
+        assert glc_amd.encode_flac_with_level(x, c["sample_rate"], c["channels"], c["level"]) == want
+        assert F.encode_flac_with_level(x, c["sample_rate"], c["channels"], c["level"]) == want
+        y, sr, ch = glc_amd.load_flac(os.path.join(gdir, c["file"]))
+        assert (sr, ch) == (c["sample_rate"], c["channels"])
+        assert np.array_equal(y, F.to_i16(x).astype(np.float32) / np.float32(32768.0))
