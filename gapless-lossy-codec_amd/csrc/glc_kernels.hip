@@ -653,13 +653,13 @@ hipError_t launch_imdct_rows(const DeviceTables &t, const DecodeRows &rows, uint
   if (M == 0) return hipSuccess;
   static const int group = [] {  // tuning knob: rows per workgroup (0 = the one-row kernel)
     const char *e = std::getenv("GLC_D1_GROUP");
-    return e ? std::atoi(e) : 4;
+    return e ? std::atoi(e) : 8;
   }();
   switch (group) {
     case 0: hipLaunchKernelGGL(k_imdct_rows, dim3(M), dim3(256), 0, s, t, rows, row_begin, M, ch, blocks); break;
     case 2: hipLaunchKernelGGL(k_imdct_group<2>, dim3((M + 1) / 2), dim3(256), 0, s, t, rows, row_begin, M, ch, blocks); break;
-    case 8: hipLaunchKernelGGL(k_imdct_group<8>, dim3((M + 7) / 8), dim3(256), 0, s, t, rows, row_begin, M, ch, blocks); break;
-    default: hipLaunchKernelGGL(k_imdct_group<4>, dim3((M + 3) / 4), dim3(256), 0, s, t, rows, row_begin, M, ch, blocks); break;
+    case 4: hipLaunchKernelGGL(k_imdct_group<4>, dim3((M + 3) / 4), dim3(256), 0, s, t, rows, row_begin, M, ch, blocks); break;
+    default: hipLaunchKernelGGL(k_imdct_group<8>, dim3((M + 7) / 8), dim3(256), 0, s, t, rows, row_begin, M, ch, blocks); break;
   }
   return hipGetLastError();
 }
