@@ -507,3 +507,45 @@ def test_unusual_channel_counts(torch_cuda, ch):
     dec = glc_amd.Decoder(ch, sr).decode(enc)
     dref, _, _ = O.decode(ref.glc)
     assert np.array_equal(bits(dec), bits(dref))
+
+
+def test_fuzz_random_configurations(torch_cuda):
+    """40 seeded random configurations (sample rate, channels, length incl. ragged, content mix,
+    amplitude from 1e-6 to clipping): `.glc` bytes and decoded PCM bits equal the oracle's."""
+    rng = np.random.default_rng(20260104)
+    rates = [8000, 11025, 16000, 22050, 32000, 44100, 48000, 88200, 96000, 176400, 192000, 12345]
+    encs, decs = {}, {}
+    for case in range(40):
+        sr = int(rng.choice(rates))
+        ch = int(rng.choice([1, 1, 2, 2, 2, 3, 5, 6, 8]))
+        n_per = int(rng.integers(513, 40000))
+        n = n_per * ch - int(rng.integers(0, ch))                  # sometimes ragged
+        if (n + ch - 1) // ch <= 512:
+            n = 513 * ch
+        kind = int(rng.integers(0, 5))
+        t = np.arange(n_per + 1, dtype=np.float64)[:, None]
+        if kind == 0:      # tones
+            f = rng.uniform(30, sr / 2.2, (1, ch))
+            x = np.sin(2 * np.pi * f * t / sr) * 0.5
+        elif kind == 1:    # noise (raw path)
+            x = rng.standard_normal((n_per + 1, ch)) * 0.3
+        elif kind == 2:    # tone, then noise, then silence
+            x = np.sin(2 * np.pi * 440.0 * t / sr) * np.ones((1, ch))
+            x[n_per // 3:2 * n_per // 3] = rng.standard_normal((2 * n_per // 3 - n_per // 3, ch)) * 0.2
+            x[2 * n_per // 3:] = 0.0
+        elif kind == 3:    # sparse clicks
+            x = np.zeros((n_per + 1, ch))
+            x[rng.integers(0, n_per, 40), rng.integers(0, ch, 40)] = rng.uniform(-1, 1, 40)
+        else:              # chirp with a DC offset
+            x = np.sin(2 * np.pi * (50.0 + 0.2 * t) * t / sr) * 0.4 + 0.1
+        amp = float(rng.choice([1e-6, 1e-3, 0.3, 1.0, 3.0]))
+        x = (x * amp).astype(np.float32).reshape(-1)[:n]
+        ref = O.encode(x, sr, ch)
+        enc_ctx = encs.setdefault(sr, glc_amd.Encoder(sr))
+        dec_ctx = decs.setdefault(sr, glc_amd.Decoder(ch, sr))
+        enc = enc_ctx.encode(x, ch)
+        assert enc.to_bytes() == ref.glc, (case, sr, ch, n, kind, amp)
+        dref, _, _ = O.decode(ref.glc)
+        assert np.array_equal(bits(dec_ctx.decode(enc)), bits(dref)), (case, sr, ch, n, kind, amp)
+    for c in list(encs.values()) + list(decs.values()):
+        c.close()
