@@ -75,6 +75,12 @@ struct glc_ctx {
   uint32_t dec_ch = 0;
   uint64_t dec_frames = 0, dec_next = 0;
   bool stream_open = false;  // glc_decode_stream_begin called, last chunk not yet delivered
+  // streaming session: chunk i is copied to the host while chunk i+1 is already being decoded
+  DevBuf stream_out;                           // two chunk-sized output buffers
+  hipEvent_t ev_dec[2] = {nullptr, nullptr};   // "kernels of the chunk in buffer b are done"
+  int stream_buf = 0;                          // buffer holding the chunk the next call delivers
+  uint64_t stream_frames = 0;                  // its frame count
+  bool stream_last = false;                    // ... and whether it is the last one (carries the tail)
 };
 
 namespace {
@@ -224,6 +230,9 @@ void glc_ctx_destroy(glc_ctx *ctx) {
   if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
   if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
   if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
+  for (hipEvent_t e : ctx->ev_dec)
+    if (e) (void)hipEventDestroy(e);
+  ctx->stream_out.release();
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   ctx->tables.release();
@@ -767,6 +776,40 @@ int glc_decode_range_device(glc_ctx *ctx, const glc_frames *in, uint64_t hop_beg
   return decode_hops_prepared(ctx, hop_begin, hop_end, d_out);
 }
 
+namespace {
+
+// Queue the kernels of the next <= 500-frame chunk of the open session into output buffer `buf`
+// (src/codec.rs:708-717: a chunk is flushed once it holds >= 500 frames; the remaining frames plus
+// the overlap tail form the last chunk, :722-732) and mark their completion with ev_dec[buf].
+int stream_launch(glc_ctx *ctx, int buf) {
+  const uint32_t ch = ctx->dec_ch;
+  const uint64_t nf = ctx->dec_frames, f0 = ctx->dec_next;
+  const uint64_t left = nf - f0;
+  const bool last = left < GLC_FRAMES_PER_CHUNK;
+  const uint64_t n = last ? left : GLC_FRAMES_PER_CHUNK;
+  const size_t slot = static_cast<size_t>(ch) * glc::kFrame;
+  const size_t cap = (static_cast<size_t>(GLC_FRAMES_PER_CHUNK) + 1) * glc::kHop * ch;  // floats per buffer
+  DeviceGuard guard(ctx->device);
+  float *blocks = static_cast<float *>(ctx->blocks.p);
+  float *dout = static_cast<float *>(ctx->stream_out.p) + static_cast<size_t>(buf) * cap;
+  if (f0 == 0) GLC_HIP(ctx, hipMemsetAsync(blocks, 0, slot * sizeof(float), ctx->stream));  // overlap = 0.0, :601
+  if (n)
+    GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, static_cast<uint32_t>(f0 * ch),
+                                        static_cast<uint32_t>(n * ch), ch, blocks + slot, ctx->stream));
+  GLC_HIP(ctx, glc::launch_overlap_add(blocks, static_cast<int64_t>(f0) - 1, nf, ch, f0, f0 + n + (last ? 1 : 0), dout,
+                                       ctx->stream));
+  if (!last)  // carry the chunk's last frame into slot 0 for the next chunk's overlap-add
+    GLC_HIP(ctx, hipMemcpyAsync(blocks, blocks + n * slot, slot * sizeof(float), hipMemcpyDeviceToDevice,
+                                ctx->stream));
+  GLC_HIP(ctx, hipEventRecord(ctx->ev_dec[buf], ctx->stream));
+  ctx->dec_next = f0 + n;
+  ctx->stream_frames = n;
+  ctx->stream_last = last;
+  return GLC_OK;
+}
+
+}  // namespace
+
 int glc_decode_stream_begin(glc_ctx *ctx, const glc_frames *in) {
   if (!ctx || !in) return fail(ctx, GLC_EINVAL, "glc_decode_stream_begin: null argument");
   ctx->stream_open = false;
@@ -774,9 +817,16 @@ int glc_decode_stream_begin(glc_ctx *ctx, const glc_frames *in) {
   if (rc != GLC_OK) return rc;
   {
     DeviceGuard guard(ctx->device);
-    GLC_HIP(ctx, ctx->blocks.reserve((static_cast<size_t>(GLC_FRAMES_PER_CHUNK) + 1) * in->channels * glc::kFrame *
-                                     sizeof(float)));
+    const size_t chunk = static_cast<size_t>(GLC_FRAMES_PER_CHUNK) + 1;
+    GLC_HIP(ctx, ctx->blocks.reserve(chunk * in->channels * glc::kFrame * sizeof(float)));
+    GLC_HIP(ctx, ctx->stream_out.reserve(2 * chunk * glc::kHop * in->channels * sizeof(float)));
+    if (!ctx->copy_stream) GLC_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (hipEvent_t &e : ctx->ev_dec)
+      if (!e) GLC_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
+  ctx->stream_buf = 0;
+  rc = stream_launch(ctx, 0);  // the first chunk is on its way before the caller asks for it
+  if (rc != GLC_OK) return rc;
   ctx->stream_open = true;
   return GLC_OK;
 }
@@ -784,19 +834,27 @@ int glc_decode_stream_begin(glc_ctx *ctx, const glc_frames *in) {
 int glc_decode_stream_next(glc_ctx *ctx, float *chunk, uint64_t cap, uint64_t *n_out, int *is_last) {
   if (!ctx || !n_out || !is_last) return fail(ctx, GLC_EINVAL, "glc_decode_stream_next: null argument");
   if (!ctx->stream_open) return fail(ctx, GLC_EINVAL, "glc_decode_stream_next: no stream open");
-  // src/codec.rs:708-717: a chunk is flushed once it holds >= 500 frames; the remaining frames
-  // plus the overlap tail form the last chunk (:722-732).  Each call decodes only its own frames.
-  const uint64_t left = ctx->dec_frames - ctx->dec_next;
-  const bool last = left < GLC_FRAMES_PER_CHUNK;
-  const uint64_t frames = last ? left : GLC_FRAMES_PER_CHUNK;
+  const int buf = ctx->stream_buf;
+  const bool last = ctx->stream_last;
   const uint64_t per_hop = static_cast<uint64_t>(glc::kHop) * ctx->dec_ch;
-  const uint64_t n = (frames + (last ? 1 : 0)) * per_hop;
+  const uint64_t n = (ctx->stream_frames + (last ? 1 : 0)) * per_hop;
   *n_out = n;
   *is_last = last ? 1 : 0;
   if (cap < n || (!chunk && n)) return fail(ctx, GLC_EINVAL, "glc_decode_stream_next: chunk buffer too small");
-  const uint64_t lo = ctx->dec_next * per_hop;
-  int rc = decode_chunk(ctx, frames, last, chunk, lo, lo + n);
-  if (rc != GLC_OK) return rc;
+  const size_t bufcap = (static_cast<size_t>(GLC_FRAMES_PER_CHUNK) + 1) * per_hop;
+  DeviceGuard guard(ctx->device);
+  // double buffering: the kernels of the following chunk are queued first, then this chunk is
+  // copied out on the copy stream as soon as its own kernels have finished
+  if (!last) {
+    const int rc = stream_launch(ctx, buf ^ 1);
+    if (rc != GLC_OK) return rc;
+  }
+  GLC_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_dec[buf], 0));
+  if (n)
+    GLC_HIP(ctx, hipMemcpyAsync(chunk, static_cast<const float *>(ctx->stream_out.p) + static_cast<size_t>(buf) * bufcap,
+                                n * sizeof(float), hipMemcpyDeviceToHost, ctx->copy_stream));
+  GLC_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+  ctx->stream_buf = buf ^ 1;
   if (last) ctx->stream_open = false;
   return GLC_OK;
 }
