@@ -70,7 +70,7 @@ struct glc_ctx {
   DevBuf pack_pairs; // compaction: packed pairs
   DevBuf pack_raw;   // compaction: raw planes
   std::string err;
-  // decode session (decode_prepare / decode_chunk): device-resident sparse rows + position
+  // decode session (decode_prepare / round_launch): device-resident sparse rows + position
   glc::DecodeRows dec_rows{};
   uint32_t dec_ch = 0;
   uint64_t dec_frames = 0, dec_next = 0;
@@ -519,7 +519,7 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
 namespace {
 
 // Upload the sparse representation of `in` and reset the overlap state: after this the stream
-// can be decoded front to back in chunks (decode_chunk).  Sparse lists are used as stored when
+// can be decoded front to back in rounds (round_launch).  Sparse lists are used as stored when
 // canonical (strictly ascending, idx < 1024 — what the encoder emits); other lists are
 // canonicalised on the host with the reference's dense-array semantics (last write wins,
 // idx >= 1024 ignored, src/codec.rs:659-665) and appended behind the stored pairs.
@@ -637,41 +637,43 @@ int decode_prepare_impl(glc_ctx *ctx, const glc_frames *in) {
   return GLC_OK;
 }
 
-// Decode frames [dec_next, dec_next + n) and copy the part of their output that falls inside
-// [want_lo, want_hi) — indices into the un-trimmed interleaved stream of (nf+1)*1024*ch samples
-// that decode_streaming emits (src/codec.rs:688-732) — to dst (dst[0] <-> stream index want_lo).
-// emit_tail: also produce the hop after the last frame, the bare overlap tail (:722-729); only
-// valid when the chunk ends at the last frame.
-int decode_chunk(glc_ctx *ctx, uint64_t n, bool emit_tail, float *dst, uint64_t want_lo, uint64_t want_hi) {
+// Queue the kernels of the next round of at most `round_frames` frames of the prepared session into
+// `dout` (hop dec_next at dout[0]) and mark their completion with `ev`.  A round that reaches the
+// last frame also produces the bare overlap tail (src/codec.rs:722-729); `flush_at_full` selects
+// the reference's streaming rule (a chunk is flushed once it holds >= 500 frames, :708-717, so a
+// stream of exactly k*500 frames ends with a tail-only chunk).  Slot 0 of the block ring carries
+// the previous round's last frame for the overlap-add.
+int round_launch(glc_ctx *ctx, uint64_t round_frames, bool flush_at_full, float *dout, hipEvent_t ev,
+                 uint64_t *frames_out, bool *last_out) {
   const uint32_t ch = ctx->dec_ch;
   const uint64_t nf = ctx->dec_frames, f0 = ctx->dec_next;
+  const uint64_t left = nf - f0;
+  const bool last = flush_at_full ? left < round_frames : left <= round_frames;
+  const uint64_t n = last ? left : round_frames;
   const size_t slot = static_cast<size_t>(ch) * glc::kFrame;  // floats per frame
   DeviceGuard guard(ctx->device);
-  GLC_HIP(ctx, ctx->blocks.reserve((std::max<uint64_t>(n, 1) + 1) * slot * sizeof(float)));
-  GLC_HIP(ctx, ctx->pcm.reserve((std::max<uint64_t>(n, 1) + 1) * glc::kHop * ch * sizeof(float)));
   float *blocks = static_cast<float *>(ctx->blocks.p);
-  float *dout = static_cast<float *>(ctx->pcm.p);
-  if (f0 == 0) {
-    // overlap = 0.0 (:601).  A grown workspace is also fresh, which is fine at frame 0 only:
-    GLC_HIP(ctx, hipMemsetAsync(blocks, 0, slot * sizeof(float), ctx->stream));
-  }
-  if (f0 + n > nf || (emit_tail && f0 + n != nf)) return fail(ctx, GLC_EINVAL, "decode_chunk: bad range");
-  const uint64_t hop_end = f0 + n + (emit_tail ? 1 : 0);
+  if (f0 == 0) GLC_HIP(ctx, hipMemsetAsync(blocks, 0, slot * sizeof(float), ctx->stream));  // overlap = 0.0, :601
   if (n)
     GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, static_cast<uint32_t>(f0 * ch),
                                         static_cast<uint32_t>(n * ch), ch, blocks + slot, ctx->stream));
-  GLC_HIP(ctx, glc::launch_overlap_add(blocks, static_cast<int64_t>(f0) - 1, nf, ch, f0, hop_end, dout,
+  GLC_HIP(ctx, glc::launch_overlap_add(blocks, static_cast<int64_t>(f0) - 1, nf, ch, f0, f0 + n + (last ? 1 : 0), dout,
                                        ctx->stream));
-  const uint64_t c_lo = f0 * glc::kHop * ch, c_hi = hop_end * glc::kHop * ch;
-  const uint64_t lo = std::max(c_lo, want_lo), hi = std::min(c_hi, want_hi);
-  if (hi > lo)
-    GLC_HIP(ctx, hipMemcpyAsync(dst + (lo - want_lo), dout + (lo - c_lo), (hi - lo) * sizeof(float),
-                                hipMemcpyDeviceToHost, ctx->stream));
-  if (!emit_tail && n)  // carry the chunk's last frame into slot 0 for the next chunk's overlap-add
+  if (!last)
     GLC_HIP(ctx, hipMemcpyAsync(blocks, blocks + n * slot, slot * sizeof(float), hipMemcpyDeviceToDevice,
                                 ctx->stream));
-  GLC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // dst is pageable: keep the copy ordered
+  GLC_HIP(ctx, hipEventRecord(ev, ctx->stream));
   ctx->dec_next = f0 + n;
+  *frames_out = n;
+  *last_out = last;
+  return GLC_OK;
+}
+
+int ensure_copy_objects(glc_ctx *ctx) {
+  DeviceGuard guard(ctx->device);
+  if (!ctx->copy_stream) GLC_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  for (hipEvent_t &e : ctx->ev_dec)
+    if (!e) GLC_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   return GLC_OK;
 }
 
@@ -729,17 +731,46 @@ int glc_decode(glc_ctx *ctx, const glc_frames *in, float *pcm_out, uint64_t cap,
   if (cap < n) return fail(ctx, GLC_EINVAL, "glc_decode: output buffer too small");
   int rc = decode_prepare(ctx, in);
   if (rc != GLC_OK) return rc;
-  // the blocks ring must not be re-allocated between chunks (slot 0 carries state): size it once
-  const uint64_t chunk = std::max<uint64_t>(1, std::min<uint64_t>(kDecodeChunkFrames, in->n_frames));
+  // Rounds of 4096 frames through two device output buffers: the kernels of round r+1 are queued
+  // before round r is copied out (on the copy stream, behind that round's event), so the D2H of
+  // one round overlaps the decode of the next.  The block ring is sized once: slot 0 carries state.
+  const uint64_t round = std::max<uint64_t>(1, std::min<uint64_t>(kDecodeChunkFrames, in->n_frames));
+  const uint64_t per_hop = static_cast<uint64_t>(glc::kHop) * in->channels;
+  const size_t bufcap = static_cast<size_t>(round + 1) * per_hop;  // floats per output buffer
   {
     DeviceGuard guard(ctx->device);
-    GLC_HIP(ctx, ctx->blocks.reserve((chunk + 1) * static_cast<size_t>(in->channels) * glc::kFrame * sizeof(float)));
+    GLC_HIP(ctx, ctx->blocks.reserve((round + 1) * static_cast<size_t>(in->channels) * glc::kFrame * sizeof(float)));
+    GLC_HIP(ctx, ctx->pcm.reserve(2 * bufcap * sizeof(float)));
   }
-  do {
-    const uint64_t left = ctx->dec_frames - ctx->dec_next;
-    rc = decode_chunk(ctx, std::min(chunk, left), left <= chunk, pcm_out, start, start + n);
-    if (rc != GLC_OK) return rc;
-  } while (ctx->dec_next < ctx->dec_frames);
+  rc = ensure_copy_objects(ctx);
+  if (rc != GLC_OK) return rc;
+  DeviceGuard guard(ctx->device);
+  float *stage = static_cast<float *>(ctx->pcm.p);
+  int buf = 0;
+  uint64_t f0 = 0, frames = 0;
+  bool last = false;
+  rc = round_launch(ctx, round, false, stage, ctx->ev_dec[0], &frames, &last);
+  if (rc != GLC_OK) return rc;
+  for (;;) {
+    const uint64_t cur_f0 = f0, cur_frames = frames;
+    const bool cur_last = last;
+    if (!cur_last) {
+      f0 += frames;
+      rc = round_launch(ctx, round, false, stage + static_cast<size_t>(buf ^ 1) * bufcap, ctx->ev_dec[buf ^ 1], &frames, &last);
+      if (rc != GLC_OK) return rc;
+    }
+    const uint64_t c_lo = cur_f0 * per_hop, c_hi = (cur_f0 + cur_frames + (cur_last ? 1 : 0)) * per_hop;
+    const uint64_t lo = std::max(c_lo, start), hi = std::min(c_hi, start + n);
+    // a stream of a single round (short clips) has nothing to overlap: copy in stream order
+    hipStream_t cs = (cur_last && cur_f0 == 0) ? ctx->stream : ctx->copy_stream;
+    if (cs != ctx->stream) GLC_HIP(ctx, hipStreamWaitEvent(cs, ctx->ev_dec[buf], 0));
+    if (hi > lo)
+      GLC_HIP(ctx, hipMemcpyAsync(pcm_out + (lo - start), stage + static_cast<size_t>(buf) * bufcap + (lo - c_lo),
+                                  (hi - lo) * sizeof(float), hipMemcpyDeviceToHost, cs));
+    GLC_HIP(ctx, hipStreamSynchronize(cs));
+    if (cur_last) break;
+    buf ^= 1;
+  }
   return GLC_OK;
 }
 
@@ -776,40 +807,6 @@ int glc_decode_range_device(glc_ctx *ctx, const glc_frames *in, uint64_t hop_beg
   return decode_hops_prepared(ctx, hop_begin, hop_end, d_out);
 }
 
-namespace {
-
-// Queue the kernels of the next <= 500-frame chunk of the open session into output buffer `buf`
-// (src/codec.rs:708-717: a chunk is flushed once it holds >= 500 frames; the remaining frames plus
-// the overlap tail form the last chunk, :722-732) and mark their completion with ev_dec[buf].
-int stream_launch(glc_ctx *ctx, int buf) {
-  const uint32_t ch = ctx->dec_ch;
-  const uint64_t nf = ctx->dec_frames, f0 = ctx->dec_next;
-  const uint64_t left = nf - f0;
-  const bool last = left < GLC_FRAMES_PER_CHUNK;
-  const uint64_t n = last ? left : GLC_FRAMES_PER_CHUNK;
-  const size_t slot = static_cast<size_t>(ch) * glc::kFrame;
-  const size_t cap = (static_cast<size_t>(GLC_FRAMES_PER_CHUNK) + 1) * glc::kHop * ch;  // floats per buffer
-  DeviceGuard guard(ctx->device);
-  float *blocks = static_cast<float *>(ctx->blocks.p);
-  float *dout = static_cast<float *>(ctx->stream_out.p) + static_cast<size_t>(buf) * cap;
-  if (f0 == 0) GLC_HIP(ctx, hipMemsetAsync(blocks, 0, slot * sizeof(float), ctx->stream));  // overlap = 0.0, :601
-  if (n)
-    GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, static_cast<uint32_t>(f0 * ch),
-                                        static_cast<uint32_t>(n * ch), ch, blocks + slot, ctx->stream));
-  GLC_HIP(ctx, glc::launch_overlap_add(blocks, static_cast<int64_t>(f0) - 1, nf, ch, f0, f0 + n + (last ? 1 : 0), dout,
-                                       ctx->stream));
-  if (!last)  // carry the chunk's last frame into slot 0 for the next chunk's overlap-add
-    GLC_HIP(ctx, hipMemcpyAsync(blocks, blocks + n * slot, slot * sizeof(float), hipMemcpyDeviceToDevice,
-                                ctx->stream));
-  GLC_HIP(ctx, hipEventRecord(ctx->ev_dec[buf], ctx->stream));
-  ctx->dec_next = f0 + n;
-  ctx->stream_frames = n;
-  ctx->stream_last = last;
-  return GLC_OK;
-}
-
-}  // namespace
-
 int glc_decode_stream_begin(glc_ctx *ctx, const glc_frames *in) {
   if (!ctx || !in) return fail(ctx, GLC_EINVAL, "glc_decode_stream_begin: null argument");
   ctx->stream_open = false;
@@ -820,12 +817,13 @@ int glc_decode_stream_begin(glc_ctx *ctx, const glc_frames *in) {
     const size_t chunk = static_cast<size_t>(GLC_FRAMES_PER_CHUNK) + 1;
     GLC_HIP(ctx, ctx->blocks.reserve(chunk * in->channels * glc::kFrame * sizeof(float)));
     GLC_HIP(ctx, ctx->stream_out.reserve(2 * chunk * glc::kHop * in->channels * sizeof(float)));
-    if (!ctx->copy_stream) GLC_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    for (hipEvent_t &e : ctx->ev_dec)
-      if (!e) GLC_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
+  rc = ensure_copy_objects(ctx);
+  if (rc != GLC_OK) return rc;
   ctx->stream_buf = 0;
-  rc = stream_launch(ctx, 0);  // the first chunk is on its way before the caller asks for it
+  // the first chunk is on its way before the caller asks for it
+  rc = round_launch(ctx, GLC_FRAMES_PER_CHUNK, true, static_cast<float *>(ctx->stream_out.p), ctx->ev_dec[0],
+                    &ctx->stream_frames, &ctx->stream_last);
   if (rc != GLC_OK) return rc;
   ctx->stream_open = true;
   return GLC_OK;
@@ -846,7 +844,9 @@ int glc_decode_stream_next(glc_ctx *ctx, float *chunk, uint64_t cap, uint64_t *n
   // double buffering: the kernels of the following chunk are queued first, then this chunk is
   // copied out on the copy stream as soon as its own kernels have finished
   if (!last) {
-    const int rc = stream_launch(ctx, buf ^ 1);
+    const int rc = round_launch(ctx, GLC_FRAMES_PER_CHUNK, true,
+                                static_cast<float *>(ctx->stream_out.p) + static_cast<size_t>(buf ^ 1) * bufcap,
+                                ctx->ev_dec[buf ^ 1], &ctx->stream_frames, &ctx->stream_last);
     if (rc != GLC_OK) return rc;
   }
   GLC_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_dec[buf], 0));
