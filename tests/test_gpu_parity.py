@@ -549,3 +549,36 @@ def test_fuzz_random_configurations(torch_cuda):
         assert np.array_equal(bits(dec_ctx.decode(enc)), bits(dref)), (case, sr, ch, n, kind, amp)
     for c in list(encs.values()) + list(decs.values()):
         c.close()
+
+
+def test_distinct_contexts_run_concurrently(torch_cuda):
+    """`&mut self` makes one Encoder / Decoder single-threaded, but distinct instances may be used
+    from different threads at once (rayon callers): four host threads, each with its own contexts
+    and its own input, produce the oracle's bytes while running interleaved on one device."""
+    import threading
+    sr = 44100
+    inputs = [(gen_tone("sine", 300.0 + 100 * i, sr, 1 + i % 2, 0.6 + 0.1 * i), 1 + i % 2) for i in range(4)]
+    refs = [O.encode(x, sr, ch) for x, ch in inputs]
+    drefs = [O.decode(r.glc)[0] for r in refs]
+    errors = []
+
+    def work(i):
+        try:
+            x, ch = inputs[i]
+            enc, dec = glc_amd.Encoder(sr), glc_amd.Decoder(ch, sr)
+            for _ in range(8):
+                ea = enc.encode(x, ch)
+                assert ea.to_bytes() == refs[i].glc
+                assert np.array_equal(bits(dec.decode(ea)), bits(drefs[i]))
+                chunks = [c.samples for c in dec.decode_streaming(ea)]
+                assert np.array_equal(bits(np.concatenate(chunks)[512:512 + x.size]), bits(drefs[i]))
+            enc.close(); dec.close()
+        except BaseException as e:  # noqa: BLE001 - reported to the main thread
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
