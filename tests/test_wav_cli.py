@@ -155,5 +155,7 @@ def test_cpp_mirror_roundtrip_matches_oracle(tmp_path, ch, family):
     assert got.size == dref.size == info["decoded"] and np.array_equal(got.view(np.uint32), dref.view(np.uint32))
     assert info["n_frames"] == ref.n_frames and info["original_length"] == x.size
     assert info["chunks"] == -(-ref.n_frames // 500)
+    from oracle import flac_oracle as F
+    assert (tmp_path / "o.f32.flac").read_bytes() == F.encode_flac_with_level(dref, sr, ch, 5)
     if family == "noise":
         assert info["raw_frames"] > 0

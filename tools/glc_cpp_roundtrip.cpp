@@ -56,6 +56,24 @@ int main(int argc, char **argv) {
       raw_frames += fr.has_raw_pcm;
       for (const auto &l : fr.sparse_coeffs_per_channel) nnz += l.size();
     }
+    // src/audio.rs + src/flac.rs twins through the C++ mirror: export the decoded samples to FLAC and
+    // WAV next to the output file and read both back (tests/test_export.rs)
+    const std::string flac_path = std::string(argv[5]) + ".flac", wav_path = std::string(argv[5]) + ".wav";
+    glc::export_to_flac(flac_path, whole, sr, ch);
+    glc::export_to_wav(wav_path, whole, sr, ch);
+    const glc::LoadedAudio from_flac = glc::load_audio_file_lossless(flac_path);
+    const glc::LoadedAudio from_wav = glc::load_audio_file_lossless(wav_path);
+    if (from_flac.sample_rate != sr || from_flac.channels != ch || from_flac.samples.size() != whole.size() ||
+        from_wav.samples != from_flac.samples) {
+      std::fprintf(stderr, "FLAC / WAV export does not read back\n");
+      return 1;
+    }
+    try {
+      glc::load_audio_file_lossless(std::string(argv[5]) + ".mp3");
+      return 1;
+    } catch (const glc::Error &e) {
+      if (e.code != GLC_EINVAL) return 1;
+    }
     std::ofstream out(argv[5], std::ios::binary);
     out.write(reinterpret_cast<const char *>(whole.data()), static_cast<std::streamsize>(whole.size() * sizeof(float)));
     const glc::AudioHeader h = loaded.header();
