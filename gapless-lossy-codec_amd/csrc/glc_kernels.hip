@@ -597,7 +597,15 @@ hipError_t launch_mdct_forward(const DeviceTables &t, const PcmView &pcm, uint64
   // The 8x8-per-lane register-staged kernel measures the same at M >= 16384 (k1_tune), so one
   // kernel serves every batch of 4096 rows or more; short clips use 64-row tiles.
   if (M < 4096) return k1::launch_sched<64, 128, 16, 4, 0, 4>(t, pcm, frame_begin, M, coef, s);  // short clips: more workgroups
-  return k1::launch_dma<4>(t, pcm, frame_begin, M, coef, s);  // 512 threads, 4x8 per lane, table tile by LDS-DMA
+  // 512 threads, 4x8 per lane, table tile by LDS-DMA; PCM by one dwordx4 per lane and stage when the
+  // channel count divides the tile height, else one dword per (row, sample)
+  switch (pcm.ch) {
+    case 1: return k1::launch_dma<4, 0, 128, 1>(t, pcm, frame_begin, M, coef, s);
+    case 2: return k1::launch_dma<4, 0, 128, 2>(t, pcm, frame_begin, M, coef, s);
+    case 4: return k1::launch_dma<4, 0, 128, 4>(t, pcm, frame_begin, M, coef, s);
+    case 8: return k1::launch_dma<4, 0, 128, 8>(t, pcm, frame_begin, M, coef, s);
+    default: return k1::launch_dma<4>(t, pcm, frame_begin, M, coef, s);
+  }
 }
 
 hipError_t launch_quantize(const DeviceTables &t, const float *coef, uint32_t M, uint32_t ch,

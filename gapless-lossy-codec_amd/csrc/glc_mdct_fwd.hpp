@@ -630,9 +630,13 @@ inline hipError_t launch_sched(const DeviceTables &t, const PcmView &pcm, uint64
 // `s_waitcnt vmcnt(1)` per stage waits for the PCM loads and the table DMA of the NEXT stage while
 // leaving the DMA of the stage after it in flight.  Same arithmetic, same order.
 // ------------------------------------------------------------------------------------------
-template <int MINW, int ABL = 0, int BM = 128>
+template <int MINW, int ABL = 0, int BM = 128, int CH = 0>
 __global__ __launch_bounds__(4 * BM) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
 void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigned M, float *__restrict__ coef) {
+  // CH = 0: one PCM dword per (row, i) and lane - any channel count.  CH = 1 / 2 / 4 / 8 (the
+  // stream's channel count, which then divides the tile height): a stage's 16 samples x CH channels
+  // of one frame are 64 * CH contiguous bytes, fetched by 4 * CH lanes with one dwordx4 each - 16x
+  // fewer cache-line touches in the texture addresser than the per-row loader.
   // BM = 128: 512 threads, 2 workgroups per CU (56 KiB LDS each).  BM = 64: 256 threads, window
   // values by scalar loads instead of LDS (36 KiB), 4 workgroups per CU - each SIMD then holds one
   // wave of four DIFFERENT workgroups, whose barrier waits do not coincide.
@@ -640,6 +644,8 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
   constexpr int kThreads = 4 * BM, kWaves = kThreads / 64;
   constexpr int kAPer = 4, kAStride = 4;
   constexpr bool kWinLds = BM == 128;
+  constexpr bool kSeg = CH != 0;  // segment loader
+  static_assert(!kSeg || (BM == 128 && (CH == 1 || CH == 2 || CH == 4 || CH == 8)), "segment loader shapes");
   constexpr int kDma = (BK * BN * 4) / (kThreads * 16);  // table-DMA instructions per thread and stage
   static_assert(BM == 128 || BM == 64, "tile heights with a hand-written schedule");
   __shared__ __attribute__((aligned(16))) float As[RING][BK * BM];
@@ -685,13 +691,31 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
   }
   const unsigned a_step = static_cast<unsigned>(kAStride * ch * 4);
   const unsigned i_bytes = static_cast<unsigned>(ch * 4);
+  // segment loader: lane -> (frame of the tile, 4 consecutive floats of its 16 x CH segment)
+  constexpr int kSegCh = kSeg ? CH : 1;
+  const int seg_fl = tid / (4 * kSegCh);       // frame within the tile
+  const int seg_o = (tid % (4 * kSegCh)) * 4;  // first float of this lane inside the segment
+  if constexpr (kSeg) {
+    const unsigned row0 = m0 + seg_fl * CH;
+    a_off = 0x80000000u;
+    if (row0 < M) {
+      const long long f = frame_begin + row0 / CH;
+      const long long e_row = (f * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * CH;
+      a_off = static_cast<unsigned>((e_row - e_base + seg_o) * 4);
+    }
+  }
   // table DMA: instruction d of wave w copies rows 2(d*kWaves + w), +1 of the stage's 16 x 128
   // tile (1 KiB, lane-linear)
   const float *b_src = tb.cos_t + n0 + static_cast<size_t>(2 * wave + (lane >> 5)) * kHopI + (lane & 31) * 4;
 
   float a_raw[kAPer];
+  f32x4 a_seg = {0.f, 0.f, 0.f, 0.f};
   auto issue_a = [&](int i0) {  // asm: hipcc must not count these loads (see lds_fetch)
     const unsigned o = a_off + static_cast<unsigned>(i0) * i_bytes;
+    if constexpr (kSeg) {
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(a_seg) : "v"(o), "s"(a_rsrc) : "memory");
+      return;
+    }
     asm volatile(
         "buffer_load_dword %0, %4, %8, 0 offen\n\t"
         "buffer_load_dword %1, %5, %8, 0 offen\n\t"
@@ -733,6 +757,15 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
     }
   };
   auto store_a = [&](int i0, int slot) {
+    if constexpr (kSeg) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = seg_o + j;  // float e of the segment: sample i = e / CH of channel e % CH
+        const int ii = e / CH;
+        As[slot][ii * BM + seg_fl * CH + e % CH] = mul_rn(a_seg[j], Ws[i0 + ii]);  // :480
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < kAPer; ++j) {
       const int ii = a_i + kAStride * j;
@@ -741,7 +774,9 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
     }
   };
   auto wait_all_but_newest_dma = [&]() {
-    if constexpr (kDma == 1)
+    if constexpr (kSeg)
+      asm volatile("s_waitcnt vmcnt(1)" : "+v"(a_seg)::"memory");
+    else if constexpr (kDma == 1)
       asm volatile("s_waitcnt vmcnt(1)" : "+v"(a_raw[0]), "+v"(a_raw[1]), "+v"(a_raw[2]), "+v"(a_raw[3])::"memory");
     else
       asm volatile("s_waitcnt vmcnt(2)" : "+v"(a_raw[0]), "+v"(a_raw[1]), "+v"(a_raw[2]), "+v"(a_raw[3])::"memory");
@@ -759,7 +794,8 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
   issue_a(0);
   issue_b(0, 0);
   load_w(0);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(a_raw[0]), "+v"(a_raw[1]), "+v"(a_raw[2]), "+v"(a_raw[3])::"memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+               : "+v"(a_raw[0]), "+v"(a_raw[1]), "+v"(a_raw[2]), "+v"(a_raw[3]), "+v"(a_seg)::"memory");
   pin_w();
   store_a(0, 0);
   issue_a(BK);
@@ -817,12 +853,13 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
   }
 }
 
-template <int MINW, int ABL = 0, int BM = 128>
+template <int MINW, int ABL = 0, int BM = 128, int CH = 0>
 inline hipError_t launch_dma(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M,
                              float *coef, hipStream_t s) {
   if (M == 0) return hipSuccess;
+  if (CH != 0 && pcm.ch != static_cast<uint32_t>(CH)) return hipErrorInvalidValue;
   const unsigned m_tiles = (M + BM - 1) / BM;
-  hipLaunchKernelGGL((k_mdct_fwd_dma<MINW, ABL, BM>), dim3(m_tiles * 8), dim3(4 * BM), 0, s, t, pcm,
+  hipLaunchKernelGGL((k_mdct_fwd_dma<MINW, ABL, BM, CH>), dim3(m_tiles * 8), dim3(4 * BM), 0, s, t, pcm,
                      static_cast<long long>(frame_begin), M, coef);
   return hipGetLastError();
 }

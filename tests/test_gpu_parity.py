@@ -582,3 +582,43 @@ def test_distinct_contexts_run_concurrently(torch_cuda):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("ch", [1, 2, 4, 8, 3])
+def test_long_ragged_streams_and_shards(torch_cuda, ch):
+    """Launches of >= 4096 rows take the LDS-DMA transform, with the dwordx4 segment loader when
+    the channel count is 1 / 2 / 4 / 8 and the per-row loader otherwise (3): ragged end (the last
+    sample frame is incomplete, the last frames run into the zero padding - partially out-of-range
+    dwordx4 loads), stream start, and shards whose buffer begins mid-stream, all against the oracle."""
+    sr = 48000
+    frames = 4096 // ch + 37
+    n = frames * 1024 * ch - 300 * ch - (ch - 1)                   # ragged: not a whole sample frame
+    rng = np.random.default_rng(ch)
+    t = np.arange(frames * 1024, dtype=np.float64)[:, None]
+    x = (np.sin(2 * np.pi * rng.uniform(60, 9000, (1, ch)) * t / sr) * 0.4).astype(np.float32)
+    x[5000:9000] = rng.standard_normal((4000, ch)).astype(np.float32) * 0.3     # some raw frames
+    x[-3000:] += rng.standard_normal((3000, ch)).astype(np.float32) * 0.2       # activity in the last frames
+    x = x.reshape(-1)[:n]
+    ref = O.encode(x, sr, ch)
+    enc = glc_amd.Encoder(sr).encode(x, ch)
+    assert enc.info().n_frames * ch >= 4096
+    assert enc.to_bytes() == ref.glc
+    whole, _ = device_encode(torch_cuda, x, sr, ch, want_coeffs=False)
+    plan = glc_amd.plan_encode(x.size, ch)
+    rec = glc_amd.lib.glc_record_bytes(ch)
+    # two shards, the first one large enough for the DMA transform; the second starts mid-stream
+    cut = plan.n_frames - 20
+    lo_hi = [(0, cut), (cut, plan.n_frames)]
+    parts = []
+    for f0, f1 in lo_hi:
+        t0 = max(0, f0 * 1024 - 512)
+        t1 = min(plan.per_channel, (f1 - 1) * 1024 - 512 + 2048)
+        r, _ = device_encode(torch_cuda, x, sr, ch, f0, f1, t0, t1 - t0, want_coeffs=False)
+        assert r.size == (f1 - f0) * rec
+        parts.append(r)
+    assert np.array_equal(np.concatenate(parts), whole)
+    # and a big shard that itself starts mid-stream (buffer base shifted, halo in front)
+    f0, f1 = 9, plan.n_frames
+    t0 = f0 * 1024 - 512
+    r, _ = device_encode(torch_cuda, x, sr, ch, f0, f1, t0, plan.per_channel - t0, want_coeffs=False)
+    assert np.array_equal(r, whole[f0 * rec:])

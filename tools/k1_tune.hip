@@ -101,6 +101,7 @@ int main(int argc, char **argv) {
       Variant{"sched pk 128x128 bk16 t8x8 w3 256thr + window in LDS", k1::launch_sched<128, 128, 16, 3, 0, 8, false, 2, true>},
       Variant{"dma   pk 128x128 bk16 t4x8 w4 512thr ring3 (table by LDS-DMA)", k1::launch_dma<4>},
       Variant{"dma   pk 128x128 ... w3", k1::launch_dma<3>},
+      Variant{"dma   pk 128x128 + segment loader (one dwordx4 per lane and stage)", k1::launch_dma<4, 0, 128, 2>},
       Variant{"dma   pk  64x128 bk16 t4x8 w4 256thr ring3, window by scalar loads", k1::launch_dma<4, 0, 64>},
       Variant{"dma   pk  64x128 ... w5", k1::launch_dma<5, 0, 64>},
       Variant{"  512thr ABL1 (no staging, no barrier)", k1::launch_sched<128, 128, 16, 4, 1, 4>},
