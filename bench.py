@@ -175,7 +175,7 @@ def main():
         for sr2 in (44100, 96000):
             e2 = glc_amd.Encoder(sr2, device=local_rank)
             reps = max(10, min(args.steps, 50))
-            for _ in range(3):
+            for _ in range(SPINUP_STEPS):  # the device clocked down while the host built this rate's tables
                 e2.encode_range_device(d_pcm.data_ptr(), me.t0, me.t_count, n_samples, CH, me.frame_begin,
                                        me.frame_end, d_rec.data_ptr())
             e2.timer_begin()
