@@ -622,3 +622,12 @@ def test_long_ragged_streams_and_shards(torch_cuda, ch):
     t0 = f0 * 1024 - 512
     r, _ = device_encode(torch_cuda, x, sr, ch, f0, f1, t0, plan.per_channel - t0, want_coeffs=False)
     assert np.array_equal(r, whole[f0 * rec:])
+    # device PCM that is only 4-byte aligned (the dwordx4 loads must not assume more)
+    d = torch_cuda.zeros(x.size + 1, dtype=torch_cuda.float32, device="cuda")
+    d[1:] = torch_cuda.from_numpy(x).cuda()
+    d_rec = torch_cuda.zeros(plan.n_frames * rec, dtype=torch_cuda.uint8, device="cuda")
+    e = glc_amd.Encoder(sr)
+    torch_cuda.cuda.synchronize()
+    e.encode_range_device(d.data_ptr() + 4, 0, plan.per_channel, x.size, ch, 0, plan.n_frames, d_rec.data_ptr(), 0)
+    e.synchronize()
+    assert np.array_equal(d_rec.cpu().numpy(), whole)
