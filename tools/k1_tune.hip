@@ -115,6 +115,9 @@ int main(int argc, char **argv) {
       Variant{"sched pk  64x128 bk32 t4x8 w4", k1::launch_sched<64, 128, 32, 4, 0, 4>},
       V(128, 128, 16, 8, 8, 2, 2), V(128, 128, 8, 8, 8, 2, 2), V(64, 128, 16, 4, 8, 2, 4),
       V(128, 128, 16, 4, 8, 2, 2), V(64, 64, 16, 4, 4, 4, 8),
+      // short clips (run with e.g. `k1_tune 86 2`): latency of the 2048-step chain, not throughput
+      V(16, 64, 16, 4, 4, 2, 1), V(16, 64, 32, 4, 4, 2, 1), V(32, 64, 16, 4, 4, 2, 1), V(16, 128, 16, 4, 4, 2, 1),
+      V(32, 128, 32, 4, 4, 2, 1), V(16, 64, 64, 4, 4, 4, 1), V(32, 64, 32, 4, 4, 4, 2),
   };
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
