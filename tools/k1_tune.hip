@@ -70,7 +70,13 @@ int main(int argc, char **argv) {
   srand(1);
   for (auto &v : h_cos_t) v = cosf((float)(rand() % 100000) * 0.001f);
   for (int i = 0; i < 2048; ++i) h_win[i] = sinf(3.14159265f * (i + 0.5f) / 2048.f);
-  for (auto &v : h_pcm) v = ((rand() % 20001) - 10000) * 1e-4f * 0.3f;
+  // argv[4]: "zero" = all-zero PCM (least switching activity), "chord" = smooth tonal data, default random
+  const std::string fill = argc > 4 ? argv[4] : "random";
+  for (size_t i = 0; i < h_pcm.size(); ++i) {
+    if (fill == "zero") h_pcm[i] = 0.0f;
+    else if (fill == "chord") h_pcm[i] = 0.05f * (sinf(0.013f * (float)(i / ch)) + sinf(0.171f * (float)(i / ch)) + sinf(0.0007f * (float)(i / ch)));
+    else h_pcm[i] = ((rand() % 20001) - 10000) * 1e-4f * 0.3f;
+  }
 
   float *d_cos_t, *d_win, *d_pcm, *d_ref, *d_out;
   CHECK(hipMalloc(&d_cos_t, h_cos_t.size() * 4));
