@@ -146,6 +146,21 @@ class Encoder {
   EncodedAudio encode(const std::vector<float> &samples, uint16_t channels) {
     return encode(samples.data(), samples.size(), channels);
   }
+  // One shard of an encode on device-resident PCM (multi-GPU hosts): frames [frame_begin, frame_end)
+  // from the PCM slice [t0, t0 + t_count) per channel, fixed-size records to d_records
+  // (glc_record_bytes(channels) each).  Queued on the context's stream; see glc_encode_range_device.
+  void encode_range_device(const float *d_pcm, uint64_t t0, uint64_t t_count, uint64_t n_samples, uint16_t channels,
+                           uint64_t frame_begin, uint64_t frame_end, void *d_records) {
+    detail::check(glc_encode_range_device(ctx_, d_pcm, t0, t_count, n_samples, channels, frame_begin, frame_end,
+                                          d_records, nullptr), ctx_);
+  }
+  // Assemble EncodedAudio from the records of all shards, gathered in frame order on this device.
+  EncodedAudio frames_from_device_records(const void *d_records, uint64_t n_frames, uint64_t n_samples, uint16_t channels) {
+    glc_frames *h = nullptr;
+    detail::check(glc_frames_from_device_records(ctx_, d_records, n_frames, n_samples, channels, &h), ctx_);
+    return EncodedAudio(h);
+  }
+  void synchronize() { detail::check(glc_ctx_synchronize(ctx_), ctx_); }
   glc_ctx *ctx() { return ctx_; }
 
  private:
@@ -170,6 +185,12 @@ class Decoder {
     out.resize(n);
     return out;
   }
+  // One shard of a decode into device memory: hops [hop_begin, hop_end) of the un-trimmed stream
+  // (n_frames + 1 hops of 1024 * channels samples); see glc_decode_range_device.
+  void decode_range_device(const EncodedAudio &encoded, uint64_t hop_begin, uint64_t hop_end, float *d_out, uint64_t cap) {
+    detail::check(glc_decode_range_device(ctx_, encoded.handle(), hop_begin, hop_end, d_out, cap), ctx_);
+  }
+  void synchronize() { detail::check(glc_ctx_synchronize(ctx_), ctx_); }
   // decode_streaming(&mut self, Arc<EncodedAudio>, _) -> Receiver<AudioChunk> — src/codec.rs:595:
   // the receiver becomes a callback invoked once per chunk, in order, the last one with is_last
   void decode_streaming(const EncodedAudio &encoded, const std::function<void(AudioChunk &&)> &on_chunk) {
