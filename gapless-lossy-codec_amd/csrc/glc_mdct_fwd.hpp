@@ -864,6 +864,133 @@ inline hipError_t launch_dma(const DeviceTables &t, const PcmView &pcm, uint64_t
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Matrix-pipe multiplier variant (tuning harness only).  `v_mfma_f32_32x32x1_2b_f32` with C = 0
+// returns exactly the bits of v_mul_f32 (tools/mfma_probe.hip), so the products of one i-step of
+// a 32-row x 64-column wave tile can come from ONE matrix instruction (two 32x32 outer products:
+// the A operand is one x value per row, the B operand one table value per column) and only the
+// separately rounded accumulation stays on the vector ALU: acc += P as v_pk_add_f32.  Same
+// arithmetic, same order.  The f32 matrix pipe does not co-issue with the VALU, so
+// this wins no issue slots; what it removes is operand traffic: 3 ds_read_b32 per 4096 MACs
+// instead of 12 ds_read_b64, and the multiply's VGPR operand reads.
+//   tile 128 x 128, 256 threads: wave w owns rows 64 (w / 2) .. +64 and columns 64 (w % 2) .. +64
+// ------------------------------------------------------------------------------------------
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+
+template <int BK, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_mdct_fwd_mx(DeviceTables tb, PcmView pcm, long long frame_begin,
+                                                          unsigned M, float *__restrict__ coef) {
+  constexpr int BM = 128, BN = 128, kThreads = 256;
+  constexpr int kAPer = BM * BK / kThreads, kAStride = kThreads / BM;
+  constexpr int kBPer = BK * BN / 4 / kThreads, kBRowsPer = kThreads / (BN / 4);
+  __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+
+  const int tid = threadIdx.x;
+  const unsigned g = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD-aware tile map
+  const int n_tile = g % 8, m_tile = g / 8;
+  const int m0 = m_tile * BM, n0 = n_tile * BN;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int r0 = (wave >> 1) * 64, c0 = (wave & 1) * 64;
+
+  const long long ch = pcm.ch;
+  const long long f0 = frame_begin + m0 / pcm.ch;
+  const long long e_first = (f0 * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * ch;
+  long long e_end = static_cast<long long>(pcm.t_count) * ch;
+  const long long n_rel = static_cast<long long>(pcm.n_samples) - static_cast<long long>(pcm.t0) * ch;
+  if (e_end > n_rel) e_end = n_rel;
+  const long long e_base = e_first < 0 ? 0 : e_first;
+  long long e_cnt = e_end - e_base;
+  if (e_cnt < 0) e_cnt = 0;
+  if (e_cnt > (1ll << 28)) e_cnt = 1ll << 28;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(pcm.p + e_base), 0, static_cast<int>(e_cnt * 4), 0x00020000);
+  const int a_r = tid % BM, a_i = tid / BM;
+  const unsigned a_row = m0 + a_r;
+  unsigned a_off = 0x80000000u;
+  if (a_row < M) {
+    const long long f = frame_begin + a_row / pcm.ch;
+    const long long c = a_row % pcm.ch;
+    const long long e_row = (f * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * ch + c;
+    a_off = static_cast<unsigned>((e_row - e_base + a_i * ch) * 4);
+  }
+  const unsigned a_step = static_cast<unsigned>(kAStride * ch * 4);
+  const float *w_ptr = tb.window + a_i;
+  const int b_r = tid / (BN / 4), b_c4 = tid % (BN / 4);
+  const float *b_ptr = tb.cos_t + n0 + static_cast<size_t>(b_r) * kHopI + b_c4 * 4;
+
+  float a_stage[kAPer];
+  float4 b_stage[kBPer];
+  auto load_stage = [&](int i0) {
+    const unsigned off0 = a_off + static_cast<unsigned>(i0) * static_cast<unsigned>(ch * 4);
+#pragma unroll
+    for (int j = 0; j < kAPer; ++j) {
+      const float x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, off0 + j * a_step, 0, 0));
+      a_stage[j] = mul_rn(x, w_ptr[i0 + kAStride * j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kBPer; ++j)
+      b_stage[j] = *reinterpret_cast<const float4 *>(b_ptr + static_cast<size_t>(i0 + kBRowsPer * j) * kHopI);
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < kAPer; ++j) As[buf][(a_i + kAStride * j) * BM + a_r] = a_stage[j];
+#pragma unroll
+    for (int j = 0; j < kBPer; ++j)
+      *reinterpret_cast<float4 *>(&Bs[buf][(b_r + kBRowsPer * j) * BN + b_c4 * 4]) = b_stage[j];
+  };
+
+  f32x32 acc0, acc1, zero;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) acc0[j] = 0.0f, acc1[j] = 0.0f, zero[j] = 0.0f;
+
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+
+  constexpr int kStages = kFrameI / BK;
+#pragma unroll 1
+  for (int s = 0; s < kStages; ++s) {
+    const int buf = s & 1;
+    load_stage(((s + 1) & (kStages - 1)) * BK);
+    const float *Ab = As[buf] + r0 + (lane & 31);
+    const float *Bb = Bs[buf] + c0 + lane;
+#pragma unroll
+    for (int ii = 0; ii < BK; ++ii) {
+      const float a0 = Ab[ii * BM], a1 = Ab[ii * BM + 32], b = Bb[ii * BN];
+      const f32x32 p0 = __builtin_amdgcn_mfma_f32_32x32x1f32(a0, b, zero, 0, 0, 0);  // fl(a*b), one per output
+      acc0 = acc0 + p0;                                                             // separately rounded add
+      const f32x32 p1 = __builtin_amdgcn_mfma_f32_32x32x1f32(a1, b, zero, 0, 0, 0);
+      acc1 = acc1 + p1;
+    }
+    store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // vgpr j of block j / 16: column = lane % 32 + 32 (j / 16), row = 8 ((j % 16) / 4) + 4 (lane / 32) + j % 4
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const f32x32 &acc = half ? acc1 : acc0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int jj = j % 16;
+      const unsigned row = m0 + r0 + half * 32 + 8 * (jj / 4) + 4 * (lane >> 5) + (jj % 4);
+      if (row >= M) continue;
+      coef[static_cast<size_t>(row) * kHopI + n0 + c0 + (lane & 31) + 32 * (j / 16)] = mul_rn(acc[j], tb.norm);
+    }
+  }
+}
+
+template <int BK, int MINW>
+inline hipError_t launch_mx(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M, float *coef,
+                            hipStream_t s) {
+  if (M == 0) return hipSuccess;
+  const unsigned m_tiles = (M + 127) / 128;
+  hipLaunchKernelGGL((k_mdct_fwd_mx<BK, MINW>), dim3(m_tiles * 8), dim3(256), 0, s, t, pcm,
+                     static_cast<long long>(frame_begin), M, coef);
+  return hipGetLastError();
+}
+
 template <int BM, int BN, int BK, int TM, int TN, int UNROLL, int MINW>
 inline hipError_t launch(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M,
                          float *coef, hipStream_t s) {

@@ -108,6 +108,10 @@ int main(int argc, char **argv) {
       Variant{"dma   pk 128x128 bk16 t4x8 w4 512thr ring3 (table by LDS-DMA)", k1::launch_dma<4>},
       Variant{"dma   pk 128x128 ... w3", k1::launch_dma<3>},
       Variant{"dma   pk 128x128 + segment loader (one dwordx4 per lane and stage)", k1::launch_dma<4, 0, 128, 2>},
+      Variant{"mx    128x128 bk16 256thr: products by v_mfma_f32_32x32x1_2b (C = 0), adds by VALU, w2", k1::launch_mx<16, 2>},
+      Variant{"mx    128x128 bk16 ... w3", k1::launch_mx<16, 3>},
+      Variant{"mx    128x128 bk16 ... w4", k1::launch_mx<16, 4>},
+      Variant{"mx    128x128 bk32 ... w2", k1::launch_mx<32, 2>},
       Variant{"dma   pk  64x128 bk16 t4x8 w4 256thr ring3, window by scalar loads", k1::launch_dma<4, 0, 64>},
       Variant{"dma   pk  64x128 ... w5", k1::launch_dma<5, 0, 64>},
       Variant{"  512thr ABL1 (no staging, no barrier)", k1::launch_sched<128, 128, 16, 4, 1, 4>},
