@@ -8,17 +8,24 @@
 // are separate instructions (v_pk_mul_f32 / v_pk_add_f32, never an FMA), there is no split-K.
 //
 // What is in this file
-//   k_mdct_fwd_dma     SHIPPED for M >= 4096 rows (BASELINE config 2 = 8192): 128x128 tile, 512 threads,
-//                      4x8 outputs per lane, table tile copied global -> LDS by LDS-DMA two stages
-//                      ahead (3-slot ring), one counted vmcnt wait per stage.
-//   k_mdct_fwd_sched   SHIPPED for short clips (M < 4096) as <64,128,16,4,0,4>.  Hand-scheduled
-//                      inline-asm i-steps (step4 / mac2rows), LDS operand prefetch, XCD-aware tile
-//                      map, register staging.  Other shapes and ABL / SCALAR / RING / WLDS are
-//                      tuning knobs (the 8x8-per-lane <128,128,16,3,0,8> ties the DMA kernel at
-//                      M >= 16384).
-//   k_mdct_fwd         tuning only: the same tiling left to hipcc's scheduler (19-24 T MAC/s).
+//   k_mdct_fwd_dma     SHIPPED for launches of >= 4096 rows (BASELINE config 2 = 8192): 128x128 tile,
+//                      512 threads, 4x8 outputs per lane, table tile copied global -> LDS by LDS-DMA
+//                      two stages ahead (3-slot ring), one counted vmcnt wait per stage; PCM tile by
+//                      one dwordx4 per lane and stage when the stream has 1 / 2 / 4 / 8 channels
+//                      (CH), one dword per (row, sample) otherwise.  BM = 64 (256 threads, window by
+//                      scalar loads) is a measured alternative, not shipped.
+//   k_mdct_fwd_sched   SHIPPED for 513..4095 rows as <64,128,16,4,0,4>.  Hand-scheduled inline-asm
+//                      i-steps (step4 / mac2rows), LDS operand prefetch, XCD-aware tile map, register
+//                      staging.  Other shapes and ABL / SCALAR / RING / WLDS are tuning knobs.
+//   k_mdct_fwd         the same tiling left to hipcc's scheduler.  SHIPPED as <32,64,32,4,4,4,2> for
+//                      launches of up to 512 rows (short clips: the latency of one workgroup's
+//                      2048-step chain is everything, and smaller lane tiles shorten the step);
+//                      larger shapes are tuning only (19-24 T MAC/s).
+//   k_mdct_fwd_mx      tuning only: products by v_mfma_f32_32x32x1_2b_f32 with C = 0 (bit-identical to
+//                      v_mul_f32, tools/mfma_probe.hip), accumulation by v_pk_add_f32.  Bit-exact,
+//                      slower: the f32 matrix instruction runs on the vector ALU's multipliers.
 // tools/k1_tune.hip times them against each other and checks every variant bit-for-bit against a
-// naive kernel; profiles/r01_k1_tune_final.txt holds the numbers.
+// naive kernel; profiles/r01_k1_tune_*.txt hold the numbers.
 #pragma once
 #include <hip/hip_runtime.h>
 
