@@ -58,6 +58,20 @@ struct Variant {
 #define V(BM, BN, BK, TM, TN, UN, MW) \
   Variant { #BM "x" #BN " bk" #BK " t" #TM "x" #TN " u" #UN " w" #MW, k1::launch<BM, BN, BK, TM, TN, UN, MW> }
 
+__global__ void k_fill_random(float *p, size_t n, unsigned seed) {
+  for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) {
+    unsigned x = seed ^ (unsigned)(i * 2654435761ull);
+    x ^= x << 13, x ^= x >> 17, x ^= x << 5;
+    p[i] = ((int)(x % 20001u) - 10000) * 1e-4f * 0.3f;
+  }
+}
+
+__global__ void k_count_diff(const unsigned *a, const unsigned *b, size_t n, unsigned long long *bad) {
+  unsigned long long local = 0;
+  for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) local += a[i] != b[i];
+  if (local) atomicAdd(bad, local);
+}
+
 int main(int argc, char **argv) {
   const int frames = argc > 1 ? atoi(argv[1]) : 4096;
   const unsigned ch = argc > 2 ? atoi(argv[2]) : 2;
@@ -93,6 +107,31 @@ int main(int argc, char **argv) {
   tb.window = d_win;
   tb.norm = 0.044194173f;
   PcmView pcm{d_pcm, 0, L, n_samples, ch};
+
+  if (fill == "soak") {
+    // soak: `reps` rounds of fresh random PCM through the shipped kernels, every output compared on
+    // the device with the naive kernel's (a rare hazard in the hand-written LDS ring / counted waits
+    // would show up as a mismatch in some round); prints one progress line per 100 rounds
+    unsigned long long *d_bad;
+    CHECK(hipMalloc(&d_bad, 8));
+    CHECK(hipMemset(d_bad, 0, 8));
+    unsigned long long total_bad = 0;
+    for (int r = 0; r < reps; ++r) {
+      hipLaunchKernelGGL(k_fill_random, dim3(1024), dim3(256), 0, 0, d_pcm, n_samples, 0x9E3779B9u * (unsigned)(r + 1));
+      hipLaunchKernelGGL(k_naive, dim3(4, M), dim3(256), 0, 0, tb, pcm, 0ll, M, d_ref);
+      const hipError_t launched = (r & 1) ? (ch == 2 ? k1::launch_dma<4, 0, 128, 2>(tb, pcm, 0, M, d_out, 0) : k1::launch_dma<4>(tb, pcm, 0, M, d_out, 0))
+                             : k1::launch_dma<4>(tb, pcm, 0, M, d_out, 0);
+      CHECK(launched);
+      hipLaunchKernelGGL(k_count_diff, dim3(1024), dim3(256), 0, 0, reinterpret_cast<const unsigned *>(d_ref),
+                         reinterpret_cast<const unsigned *>(d_out), (size_t)M * 1024, d_bad);
+      if (r % 100 == 99 || r == reps - 1) {
+        CHECK(hipMemcpy(&total_bad, d_bad, 8, hipMemcpyDeviceToHost));
+        printf("soak round %d: %llu mismatching coefficients so far\n", r + 1, total_bad);
+        fflush(stdout);
+      }
+    }
+    return total_bad ? 1 : 0;
+  }
 
   hipLaunchKernelGGL(k_naive, dim3(4, M), dim3(256), 0, 0, tb, pcm, 0ll, M, d_ref);
   CHECK(hipDeviceSynchronize());
