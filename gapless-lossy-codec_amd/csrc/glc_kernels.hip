@@ -663,10 +663,9 @@ hipError_t launch_pack_rows(const uint8_t *records, uint32_t M, uint32_t ch, con
 hipError_t launch_imdct_rows(const DeviceTables &t, const DecodeRows &rows, uint32_t row_begin,
                              uint32_t M, uint32_t ch, float *blocks, hipStream_t s) {
   if (M == 0) return hipSuccess;
-  static const int group = [] {  // tuning knob: rows per workgroup (0 = the one-row kernel)
-    const char *e = std::getenv("GLC_D1_GROUP");
-    return e ? std::atoi(e) : 8;
-  }();
+  // tuning / cross-check knob, read per launch: rows per workgroup (0 = the one-row kernel)
+  const char *group_env = std::getenv("GLC_D1_GROUP");
+  const int group = group_env ? std::atoi(group_env) : 8;
   switch (group) {
     case 0: hipLaunchKernelGGL(k_imdct_rows, dim3(M), dim3(256), 0, s, t, rows, row_begin, M, ch, blocks); break;
     case 2: hipLaunchKernelGGL(k_imdct_group<2>, dim3((M + 1) / 2), dim3(256), 0, s, t, rows, row_begin, M, ch, blocks); break;
