@@ -3,17 +3,23 @@
 
 Workload (BASELINE.json configs[1]): batch-encode 4096 frames x 1024 samples of 48 kHz stereo
 synthetic PCM per GPU.  A "step" is one pass of the hot path (K1 windowed MDCT, K2 scale /
-thresholds / quantiser, K3 raw decision + raw plane) over that batch, from interleaved f32 PCM
-resident in HBM to fixed-size frame records resident in HBM.  With N > 1 ranks the stream is
-N x 4096 frames long and rank r encodes the contiguous frame range [4096 r, 4096 (r+1)) from its
-own PCM shard + halo (weak scaling, no data-path collective); the north_star's single gather of
-the records to rank 0 happens once after the timed steps and is reported separately.
+thresholds / quantiser / raw decision) over that batch, from interleaved f32 PCM resident in HBM to
+fixed-size frame records resident in HBM.  With N > 1 ranks the stream is N x 4096 frames long and
+rank r encodes the contiguous frame range [4096 r, 4096 (r+1)) from its own PCM shard + halo (weak
+scaling, no data-path collective inside a step); the job then ends with the north_star's single
+gather: every rank compacts its records on its device and the compact blobs go to rank 0.  For
+N > 1 that gather is INSIDE the timed region (`value` = all samples / (K steps + one gather));
+the gather-free figure is reported beside it.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line.  With N > 1 and no
+WORLD_SIZE in the environment this process starts the N ranks itself (before touching the GPU) and
+relays rank 0's line; under `torch.distributed.run` it is one of the ranks.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,7 +33,10 @@ HOP = 1024
 FLOP_PER_SAMPLE = 4096.0          # 2048 mul + 2048 add per channel-sample
 BYTES_PER_SAMPLE = 4.0 + 2.0 + 6.0 / 1024.0  # f32 in + dense i16 out + {scale, nnz} per 1024
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-F32_PEAK_TFLOPS = 157.3           # f32 MFMA dense peak == f32 vector peak (MI355X_MICROARCH.md)
+F32_PEAK_TFLOPS = 157.3           # f32 vector peak with FMA = 2 flop (MI355X_MICROARCH.md)
+F32_UNFUSED_TFLOPS = F32_PEAK_TFLOPS / 2.0  # separately rounded mul + add: one flop per issue slot
+K1_KERNEL = "glc::k1::k_mdct_fwd_dma<4, 0, 128, 2>"   # name in rocprofv3's kernel trace
+D1_KERNEL = "glc::k_imdct_chan<8>"
 
 
 def make_shard_pcm(np, rank, world):
@@ -41,18 +50,49 @@ def make_shard_pcm(np, rank, world):
     plan = glc_amd.plan_encode(n_samples, CH)
     assert plan.n_frames == n_frames
     me = shard.plan_shards(n_frames, L, world)[rank]
+    return chord(np, me.t0, me.t_count), me, n_samples
+
+
+def chord(np, t0, t_count):
     rng = np.random.RandomState(7)
-    t = (np.arange(me.t0, me.t0 + me.t_count, dtype=np.float64)) / SR
-    x = np.zeros((me.t_count, CH), np.float64)
+    t = (np.arange(t0, t0 + t_count, dtype=np.float64)) / SR
+    x = np.zeros((t_count, CH), np.float64)
     for c in range(CH):
         freqs = rng.uniform(80.0, 8000.0, 16)
         phases = rng.uniform(0, 2 * np.pi, 16)
         for f, p in zip(freqs, phases):
             x[:, c] += 0.05 * np.sin(2 * np.pi * f * t + p)
-    return x.astype(np.float32).reshape(-1), me, n_samples
+    return x.astype(np.float32).reshape(-1)
 
 
 SPINUP_STEPS = 150  # untimed, before the --warmup steps
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` as the driver calls it: this process has made no GPU call; it
+    starts N fresh ranks under torch.distributed.run, relays rank 0's JSON line and exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for ln in p.stdout.decode("utf-8", "replace").splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+    if line is not None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    if p.returncode != 0 or line is None:
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank run failed (rc {p.returncode})\n")
+        raise SystemExit(p.returncode or 1)
 
 
 def main():
@@ -62,6 +102,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a
     # version banner to stdout when the first communicator is created), so everything written to
     # fd 1 during the run is sent to stderr and the JSON line goes to the saved descriptor.
@@ -81,20 +123,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU fallback)"
-    # GLC_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks
-    # then share devices and the gather goes through host memory); the real run uses nccl = RCCL.
-    backend = os.environ.get("GLC_BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
+    # The real run is one rank per GPU over nccl = RCCL.  On a box with fewer GPUs than ranks (the
+    # one-GPU development box) the ranks share devices and the gather goes through host memory
+    # (gloo): a rehearsal of the N > 1 code path, labelled as such in the output.
+    backend = os.environ.get("GLC_BENCH_BACKEND", "nccl" if ndev >= world else "gloo")
     if backend != "nccl" or ndev <= local_rank:
-        # rehearsal on fewer GPUs than ranks, or a launcher that exposes one device per rank
-        # (HIP_VISIBLE_DEVICES): index within what this process can see
         local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
-    # GLC_BENCH_FORCE_DIST=1 takes the collective path (init, barrier, all_reduce, gather) even with
-    # one rank: the only way to rehearse RCCL itself on a one-GPU box
+    # GLC_BENCH_FORCE_DIST=1 takes the collective path even with one rank: the only way to
+    # rehearse RCCL itself on a one-GPU box
     dist_on = world > 1 or os.environ.get("GLC_BENCH_FORCE_DIST") == "1"
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -111,6 +151,8 @@ def main():
     rec_bytes = glc_amd.lib.glc_record_bytes(CH)
     d_rec = torch.empty(me.n_frames * rec_bytes, dtype=torch.uint8, device="cuda")
     d_coef = torch.empty((me.n_frames * CH, 1024), dtype=torch.float32, device="cuda")
+    blob_cap = glc_amd.compact_bound(CH, me.n_frames)
+    d_blob = torch.empty(blob_cap, dtype=torch.uint8, device="cuda")
     enc = glc_amd.Encoder(SR, device=local_rank)  # owns the HIP stream its kernels run on
     torch.cuda.synchronize()
 
@@ -124,27 +166,71 @@ def main():
         torch.cuda.synchronize()
         enc.synchronize()
 
+    def gather_once():
+        """The job's single gather: compact this rank's records on the device, send the blob."""
+        info = enc.compact_device_records(d_rec.data_ptr(), me.n_frames, CH, d_blob.data_ptr(), blob_cap)
+        blob = d_blob[:info.bytes]
+        got = shard.gather_compact(blob if backend == "nccl" else blob.cpu())
+        torch.cuda.synchronize()
+        return info, got
+
     # clocks: the device idles at a low DVFS state and needs some tens of milliseconds of load to
     # settle; a short spin-up (reported in config) keeps small --steps runs comparable to long ones
     for _ in range(SPINUP_STEPS):
         step()
     for _ in range(args.warmup):
         step()
+    if dist_on:
+        enc.synchronize()
+        gather_once()        # untimed: communicator / buffers of the collective exist before the clock starts
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     enc.synchronize()
     torch.cuda.synchronize()
+    t_steps = time.perf_counter() - t0
+    info = blobs = None
+    if dist_on:
+        info, blobs = gather_once()
     elapsed = time.perf_counter() - t0
     if dist_on:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        tt = torch.tensor([elapsed, t_steps], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed, t_steps = float(tt[0].item()), float(tt[1].item())
     barrier()
 
     samples_per_step = FRAMES_PER_GPU * HOP * CH * world
     value = samples_per_step * args.steps / elapsed / 1e6
+
+    # ---- the gathered blobs assemble into one valid stream (rank 0) ----------------------
+    gather = None
+    if dist_on:
+        gather = {"ms": round((elapsed - t_steps) * 1e3, 3),
+                  "in_timed_region": True,
+                  "value_excluding_gather": round(samples_per_step * args.steps / t_steps / 1e6, 2),
+                  "backend": "nccl (RCCL over xGMI)" if backend == "nccl"
+                  else f"{backend} (rehearsal: {world} ranks on {ndev} GPU(s), blobs through host memory)",
+                  "what": "per rank: device compaction of its 4096 records (scan + ballot pack) + size exchange "
+                          "(8 B per rank) + one gather of the compact blobs to rank 0"}
+        if rank == 0:
+            sizes = [int(b.numel()) for b in blobs]
+            gather["bytes_to_root"] = int(sum(sizes[1:]))
+            gather["dense_record_bytes_to_root"] = int(rec_bytes * FRAMES_PER_GPU * (world - 1))
+            ea = shard.assemble_frame_shards(blobs, SR, n_samples, CH)
+            gather["assembled_frames"] = int(ea.info().n_frames)
+            gather["assembled_raw_frames"] = int(ea.info().n_raw_frames)
+            assert gather["assembled_frames"] == FRAMES_PER_GPU * world
+            # the assembled .glc equals a single-rank encode of the same stream (rehearsal sizes only:
+            # the root re-generates and re-encodes the WHOLE stream for this)
+            verify = os.environ.get("GLC_BENCH_VERIFY", "1" if world <= 2 else "0") == "1"
+            gather["assembled_equals_single_rank"] = None
+            if verify:
+                whole = chord(np, 0, FRAMES_PER_GPU * world * HOP)
+                single = enc.encode(whole, CH)
+                gather["assembled_equals_single_rank"] = bool(single.to_bytes() == ea.to_bytes())
+                assert gather["assembled_equals_single_rank"], "gathered stream differs from the single-rank encode"
+                del whole, single
 
     # ---- dominant kernel (K1, forward MDCT) timed alone with events on ITS stream -------
     k1_reps = max(10, min(args.steps, 50))
@@ -153,6 +239,8 @@ def main():
         enc.mdct_forward_device(d_pcm.data_ptr(), me.t0, me.t_count, n_samples, CH, me.frame_begin,
                                 me.frame_end, d_coef.data_ptr())
 
+    for _ in range(10):
+        step()
     k1()
     enc.timer_begin()          # HIP events on the stream the kernels are launched on
     for _ in range(k1_reps):
@@ -190,43 +278,22 @@ def main():
         step()
         enc.synchronize()
 
-    # ---- the single gather (north_star), once, after the timed steps --------------------
-    gather = None
-    if dist_on:
-        shards = shard.plan_shards(FRAMES_PER_GPU * world, FRAMES_PER_GPU * world * HOP, world)
-        barrier()
-        g0 = time.perf_counter()
-        allrec = shard.gather_records(d_rec if backend == "nccl" else d_rec.cpu(), shards, rec_bytes)
-        torch.cuda.synchronize()
-        g_ms = (time.perf_counter() - g0) * 1e3
-        gather = {"ms": round(g_ms, 3), "bytes_to_root": int(rec_bytes * FRAMES_PER_GPU * (world - 1)),
-                  "backend": "nccl(rccl over xGMI)" if backend == "nccl" else backend,
-                  # the whole job = K batches + this one gather: throughput with it counted in
-                  "value_including_gather": round(samples_per_step * args.steps / (elapsed + g_ms * 1e-3) / 1e6, 2)}
-        if rank == 0:  # the gathered records assemble into one valid stream of world x 4096 frames
-            if allrec.is_cuda:  # compact on the root's device, only the bitstream payload crosses PCIe
-                ea = enc.frames_from_device_records(allrec.data_ptr(), FRAMES_PER_GPU * world, n_samples, CH)
-            else:
-                ea = glc_amd.EncodedAudio.from_records(SR, n_samples, CH, allrec.numpy())
-            gather["assembled_frames"] = int(ea.info().n_frames)
-            gather["assembled_raw_frames"] = int(ea.info().n_raw_frames)
-        if rank == 0:
-            assert allrec.numel() == rec_bytes * FRAMES_PER_GPU * world
-
     # ---- sanity: records of this run assemble into a valid stream (rank 0, own shard) ----
-    info = None
+    encoded = None
     if rank == 0 and world == 1:
         ea = glc_amd.EncodedAudio.from_records(SR, n_samples, CH, d_rec.cpu().numpy())
         i = ea.info()
-        info = {"n_frames": int(i.n_frames), "raw_frames": int(i.n_raw_frames), "total_nnz": int(i.total_nnz),
-                "glc_bytes": int(glc_amd.lib.glc_serialized_size(ea._h))}
+        cinfo = enc.compact_device_records(d_rec.data_ptr(), me.n_frames, CH, d_blob.data_ptr(), blob_cap)
+        encoded = {"n_frames": int(i.n_frames), "raw_frames": int(i.n_raw_frames), "total_nnz": int(i.total_nnz),
+                   "glc_bytes": int(glc_amd.lib.glc_serialized_size(ea._h)),
+                   "compact_blob_bytes": int(cinfo.bytes), "dense_record_bytes": int(rec_bytes * me.n_frames)}
 
     # ---- PCIe-inclusive host boundary (Encoder::encode from host memory + save_encoded bytes);
     # reported beside the headline, never as `value` -------------------------------------------
     host_boundary = None
     if rank == 0 and world == 1:
         best = None
-        for _ in range(3):
+        for _ in range(5):
             h0 = time.perf_counter()
             ea_h = enc.encode(pcm_host, CH)
             h1 = time.perf_counter()
@@ -234,10 +301,15 @@ def main():
             h2 = time.perf_counter()
             if best is None or h1 - h0 < best[0]:
                 best = (h1 - h0, h2 - h1, len(blob))
+        pcm_bytes = pcm_host.size * 4
         host_boundary = {"encode_ms": round(best[0] * 1e3, 3), "serialize_ms": round(best[1] * 1e3, 3),
                          "Msamples/s": round(FRAMES_PER_GPU * HOP * CH / best[0] / 1e6, 1), "glc_bytes": best[2],
-                         "note": "host f32 PCM (pageable) -> H2D -> kernels -> device-side compaction -> D2H of "
-                                 "pairs -> EncodedAudio; best of 3"}
+                         "h2d_bytes": int(pcm_bytes),
+                         "pcie_gen5_x16_GBs": 63.0,
+                         "h2d_floor_ms_at_pcie_peak": round(pcm_bytes / 63.0e9 * 1e3, 3),
+                         "note": "host f32 PCM (pageable, caller-owned) -> H2D in sub-rounds overlapped with the "
+                                 "kernels -> device-side compaction -> one D2H of the compact blob through pinned "
+                                 "memory -> EncodedAudio; best of 5"}
 
     # ---- decode of the same batch, device-resident (sparse rows resident -> interleaved PCM in
     # HBM): D1 sparse IMDCT + window, D2 overlap-add.  Beside the headline, never `value`. ---------
@@ -246,20 +318,39 @@ def main():
         ea_d = glc_amd.EncodedAudio.from_records(SR, n_samples, CH, d_rec.cpu().numpy())
         dec = glc_amd.Decoder(CH, SR, device=local_rank)
         d_all = torch.empty((FRAMES_PER_GPU + 1) * HOP * CH, dtype=torch.float32, device="cuda")
+        d_blk = torch.empty((FRAMES_PER_GPU * CH, 2048), dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()
         reps = max(5, min(args.steps, 20))
-        dec.decode_device(ea_d, d_all.data_ptr(), d_all.numel())   # includes the one-off upload
+        t_u0 = time.perf_counter()
+        dec.decode_device(ea_d, d_all.data_ptr(), d_all.numel())   # first call: row prep + upload
+        dec.synchronize()
+        first_ms = (time.perf_counter() - t_u0) * 1e3
+        for _ in range(30):
+            dec.decode_device(ea_d, d_all.data_ptr(), d_all.numel())
         dec.synchronize()
         t_d0 = time.perf_counter()
         for _ in range(reps):
             dec.decode_device(ea_d, d_all.data_ptr(), d_all.numel())
         dec.synchronize()
         d_ms = (time.perf_counter() - t_d0) * 1e3 / reps
-        nnz_row = ea_d.info().total_nnz / (FRAMES_PER_GPU * CH)
+        dec.imdct_device(ea_d, 0, FRAMES_PER_GPU, d_blk.data_ptr())
+        dec.timer_begin()
+        for _ in range(reps):
+            dec.imdct_device(ea_d, 0, FRAMES_PER_GPU, d_blk.data_ptr())
+        d1_ms = dec.timer_end() / reps
+        total_nnz = int(ea_d.info().total_nnz)
+        nnz_row = total_nnz / (FRAMES_PER_GPU * CH)
+        d1_tflops = total_nnz * 2048.0 * 2.0 / (d1_ms * 1e-3) / 1e12
         decode = {"Msamples/s": round(FRAMES_PER_GPU * HOP * CH / (d_ms * 1e-3) / 1e6, 1), "ms": round(d_ms, 4),
-                  "nnz_per_row": round(nnz_row, 1),
-                  "note": "glc_decode_device per call: host canonical-row prep + 3.9 MB upload + D1 + D2 "
-                          "(wall clock); kernels alone are in profiles/"}
+                  "first_call_ms": round(first_ms, 3), "nnz_per_row": round(nnz_row, 1),
+                  "roofline": {"bound": "valu", "kernel": D1_KERNEL, "achieved": round(d1_tflops, 3),
+                               "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(d1_tflops / F32_PEAK_TFLOPS, 4),
+                               "frac_of_unfused_ceiling": round(d1_tflops / F32_UNFUSED_TFLOPS, 4),
+                               "ms_per_launch": round(d1_ms, 4),
+                               "flop": "2 x 2048 x stored non-zeros (adding the +0.0 products of absent "
+                                       "coefficients is the identity, so they are not work)"},
+                  "note": "glc_decode_device per call with the stream's sparse rows already resident on the device "
+                          "(D1 + D2, wall clock); first_call_ms includes the one-off row preparation + upload"}
         dec.close()
 
     # ---- CPU baseline: the oracle (a port of src/codec.rs) on this box's cores, rank 0, N=1
@@ -274,11 +365,16 @@ def main():
                "sample": f"all {nfr} frames of the same 48 kHz stereo batch, best of 2 passes, {cores} threads "
                          f"({sec:.2f} s wall); C restatement of src/codec.rs (no Rust toolchain in the image)"}
 
-    traffic = None
+    # HBM-side traffic of K1 comes from PMC counters (separate rocprofv3 --pmc passes over this same
+    # command, summarised by tools/pmc_traffic.py into profiles/): it cannot be measured from inside
+    # the run, so the line names the file and the commit it was taken at.
+    traffic = traffic_source = None
     tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("hbm_bytes_per_launch")
+            traffic_source = f"profiles/k1_traffic.json @{tj.get('commit', 'unknown')} ({tj.get('method', 'pmc')})"
         except Exception:
             traffic = None
 
@@ -300,26 +396,31 @@ def main():
                                    "48 kHz stereo synthetic PCM (16-tone chord per channel) per GPU",
                        "frames_per_gpu": FRAMES_PER_GPU, "channels": CH, "sample_rate": SR,
                        "samples_per_step": samples_per_step,
-                       "sharding": f"frame-range x{world}, one gather of records at the end",
+                       "sharding": f"frame-range x{world}" + (", one gather of the compact blobs at the end "
+                                                               "(inside the timed region)" if dist_on else ""),
                        "spinup_steps": SPINUP_STEPS},
-            "roofline": {"bound": "mfma", "kernel": "k_mdct_fwd", "achieved": round(k1_tflops, 3),
+            "roofline": {"bound": "valu", "kernel": K1_KERNEL, "achieved": round(k1_tflops, 3),
                          "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(k1_tflops / F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "frac": round(k1_tflops / F32_PEAK_TFLOPS, 4),
+                         "frac_of_unfused_ceiling": round(k1_tflops / F32_UNFUSED_TFLOPS, 4),
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "ms_per_launch": round(k1_ms, 4),
-                         "note": "f32 compute roofline (f32 MFMA dense peak = f32 VALU peak = 157.3 TF); "
-                                 "4096 flop/sample = 2048 separately rounded mul + 2048 add. Bit-exact "
-                                 "parity forbids FMA, so a VALU-only kernel tops out at 50 % of this peak."},
+                         "note": "f32 vector-ALU issue roofline (157.3 TFLOP/s counts an FMA as 2 flop); 4096 "
+                                 "flop/sample = 2048 separately rounded mul + 2048 add.  Bit-exact parity forbids "
+                                 "FMA and MFMA accumulation, so the ceiling of this kernel is 78.65 TFLOP/s "
+                                 "(frac_of_unfused_ceiling)."},
             "roofline_hbm": {"bound": "hbm", "achieved": round(k1_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(k1_gbs / HBM_PEAK_GBS, 5), "pct_hbm_roofline": round(100 * k1_gbs / HBM_PEAK_GBS, 3),
                              "note": "BASELINE metric's '% HBM roofline': 6.006 algorithmic B/sample; the "
                                      "path is compute-bound (SURVEY F4), cap under parity = 1.44 %"},
             "cpu_baseline": cpu,
+            "vs_cpu_baseline": round(value / cpu["value"], 1) if cpu else None,
             "step_ms_events": round(step_ev_ms, 4),
             "other_sample_rates": other_rates,
             "host_boundary": host_boundary,
             "decode": decode,
             "gather": gather,
-            "encoded": info,
+            "encoded": encoded,
         }
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

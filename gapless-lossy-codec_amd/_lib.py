@@ -26,6 +26,15 @@ class GlcInfo(C.Structure):
     ]
 
 
+class GlcCompactInfo(C.Structure):
+    _fields_ = [
+        ("n_frames", C.c_uint64),
+        ("n_pairs", C.c_uint64),
+        ("n_raw_rows", C.c_uint64),
+        ("bytes", C.c_uint64),
+    ]
+
+
 class GlcPlan(C.Structure):
     _fields_ = [
         ("n_frames", C.c_uint64),
@@ -59,10 +68,17 @@ SIGNATURES = {
     "glc_frames_from_records": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint16, _vp, C.c_uint64,
                                           C.POINTER(_vp)]),
     "glc_frames_from_device_records": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint16, C.POINTER(_vp)]),
+    "glc_compact_bound": (C.c_uint64, [C.c_uint16, C.c_uint64]),
+    "glc_compact_device_records": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint16, _vp, C.c_uint64,
+                                             C.POINTER(GlcCompactInfo)]),
+    "glc_compact_records": (C.c_int, [_vp, C.c_uint64, C.c_uint16, _vp, C.c_uint64, C.POINTER(GlcCompactInfo)]),
+    "glc_frames_from_compact": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint16, C.POINTER(_vp),
+                                          C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(_vp)]),
     "glc_decoded_len": (C.c_uint64, [_vp]),
     "glc_decode": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "glc_decode_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "glc_decode_range_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64]),
+    "glc_imdct_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _vp]),
     "glc_decode_stream_begin": (C.c_int, [_vp, _vp]),
     "glc_decode_stream_next": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_int)]),

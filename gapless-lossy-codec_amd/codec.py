@@ -21,7 +21,7 @@ from typing import Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from ._lib import GLC_EINVAL, GlcError, GlcInfo, GlcPlan, check, lib
+from ._lib import GLC_EINVAL, GlcCompactInfo, GlcError, GlcInfo, GlcPlan, check, lib
 
 FRAME_SIZE = 2048        # src/codec.rs:15
 HOP_SIZE = 1024          # src/codec.rs:16
@@ -161,6 +161,40 @@ class EncodedAudio:
         return EncodedAudio(out.value)
 
 
+    @staticmethod
+    def from_compact(sample_rate: int, n_samples: int, channels: int, blobs) -> "EncodedAudio":
+        """Assemble from compact blobs (one per shard, frame order): glc_frames_from_compact.
+        Each blob is a bytes-like / uint8 array as produced by Encoder.compact_device_records or
+        compact_records."""
+        arrs = [np.ascontiguousarray(np.frombuffer(b, np.uint8) if isinstance(b, (bytes, bytearray, memoryview))
+                                     else b, np.uint8).reshape(-1) for b in blobs]
+        n = len(arrs)
+        ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in arrs])
+        sizes = (C.c_uint64 * max(n, 1))(*[a.size for a in arrs])
+        out = C.c_void_p()
+        check(lib.glc_frames_from_compact(sample_rate, n_samples, channels, ptrs, sizes, n, C.byref(out)))
+        return EncodedAudio(out.value)
+
+
+def compact_bound(channels: int, n_frames: int) -> int:
+    """Capacity a compact-blob buffer needs for n_frames frames (glc_compact_bound)."""
+    return int(lib.glc_compact_bound(channels, n_frames))
+
+
+def compact_records(records: np.ndarray, channels: int) -> np.ndarray:
+    """Host twin of the device compaction (glc_compact_records): records -> compact blob bytes."""
+    records = np.ascontiguousarray(records, np.uint8).reshape(-1)
+    rec = lib.glc_record_bytes(channels)
+    if rec == 0 or records.size % rec:
+        raise GlcError(GLC_EINVAL, "record buffer is not a whole number of records")
+    nf = records.size // rec
+    blob = np.empty(compact_bound(channels, nf), np.uint8)
+    info = GlcCompactInfo()
+    check(lib.glc_compact_records(records.ctypes.data_as(C.c_void_p), nf, channels, blob.ctypes.data_as(C.c_void_p),
+                                  blob.size, C.byref(info)))
+    return blob[:info.bytes].copy()
+
+
 def plan_encode(n_samples: int, channels: int) -> GlcPlan:
     """Frame count / padding of Encoder::encode (src/codec.rs:433-455); raises where it panics."""
     p = GlcPlan()
@@ -243,6 +277,14 @@ class Encoder(_Ctx):
                                                  C.byref(out)), self._h)
         return EncodedAudio(out.value)
 
+    def compact_device_records(self, d_records: int, n_frames: int, channels: int, d_blob: int, cap: int) -> GlcCompactInfo:
+        """Pack n_frames device records into the compact blob at device address d_blob
+        (glc_compact_device_records); synchronises; returns the sizes (info.bytes travel)."""
+        info = GlcCompactInfo()
+        check(lib.glc_compact_device_records(self._h, C.c_void_p(d_records) if d_records else None, n_frames, channels,
+                                             C.c_void_p(d_blob), cap, C.byref(info)), self._h)
+        return info
+
     def mdct_forward_device(self, d_pcm: int, t0: int, t_count: int, n_samples: int, channels: int,
                             frame_begin: int, frame_end: int, d_coeffs: int) -> None:
         """Window + mdct_block only (src/codec.rs:476-485) for a frame range, device-resident."""
@@ -300,6 +342,11 @@ class Decoder(_Ctx):
         """One shard of the decode: hops [hop_begin, hop_end) of the un-trimmed stream into device
         memory at address d_out (glc_decode_range_device).  Queued, not synchronised."""
         check(lib.glc_decode_range_device(self._h, encoded._h, hop_begin, hop_end, C.c_void_p(d_out), cap), self._h)
+
+    def imdct_device(self, encoded: EncodedAudio, frame_begin: int, frame_end: int, d_blocks: int) -> None:
+        """Dequant + imdct_block + window (src/codec.rs:651-675) alone for a frame range:
+        d_blocks[(frame - frame_begin) * ch + c][2048] on the device (glc_imdct_device)."""
+        check(lib.glc_imdct_device(self._h, encoded._h, frame_begin, frame_end, C.c_void_p(d_blocks)), self._h)
 
     def decode_streaming(self, encoded: EncodedAudio, progress_sender=None) -> Iterator[AudioChunk]:
         """Decoder::decode_streaming — src/codec.rs:595-741: yields AudioChunk until is_last."""

@@ -50,6 +50,27 @@ struct DevBuf {
   }
 };
 
+// Pinned host staging buffer (grows on demand): device <-> host copies through it run at PCIe
+// speed and truly asynchronously, which pageable memory does not give.
+struct HostBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
 struct glc_ctx {
   int device = 0;
   uint32_t sample_rate = 0;
@@ -66,12 +87,13 @@ struct glc_ctx {
   DevBuf records;    // staging for host-boundary encode
   DevBuf blocks;     // decode: windowed IMDCT blocks [(chunk+1)][ch][2048]
   DevBuf dec_meta;   // decode: pairs / offsets / scales / raw pool
-  DevBuf pack_meta;  // compaction: loc, blk, blk_raw, totals, scales, is_raw, row_off
-  DevBuf pack_pairs; // compaction: packed pairs
-  DevBuf pack_raw;   // compaction: raw planes
+  DevBuf pack_meta;  // compaction scratch: loc, blk, blk_raw, totals
+  DevBuf pack_blob;  // compaction: the compact blob of glc_encode / glc_frames_from_device_records
+  HostBuf host_stage;  // pinned: the blob on its way to the host
   std::string err;
   // decode session (decode_prepare / round_launch): device-resident sparse rows + position
   glc::DecodeRows dec_rows{};
+  uint64_t dec_uid = 0;  // glc_frames::uid whose rows dec_meta holds (0: none)
   uint32_t dec_ch = 0;
   uint64_t dec_frames = 0, dec_next = 0;
   bool stream_open = false;  // glc_decode_stream_begin called, last chunk not yet delivered
@@ -242,8 +264,8 @@ void glc_ctx_destroy(glc_ctx *ctx) {
   ctx->blocks.release();
   ctx->dec_meta.release();
   ctx->pack_meta.release();
-  ctx->pack_pairs.release();
-  ctx->pack_raw.release();
+  ctx->pack_blob.release();
+  ctx->host_stage.release();
   delete ctx;
 }
 
@@ -308,6 +330,8 @@ int glc_encode_range_device(glc_ctx *ctx, const float *d_pcm, uint64_t t0, uint6
   if (frame_begin > frame_end || frame_end > plan.n_frames)
     return fail(ctx, GLC_EINVAL, "glc_encode_range_device: frame range out of bounds");
   const uint32_t ch = channels;
+  if (d_coeffs && (frame_end - frame_begin) * ch > 0xFFFFFFFFull)
+    return fail(ctx, GLC_EINVAL, "glc_encode_range_device: range too large for one coefficient tap");
   // The shard must hold every real sample the frame range reads:
   // per-channel t in [1024*f0 - 512, 1024*(f1-1) - 512 + 2048) clipped to the stream.
   if (frame_end > frame_begin) {
@@ -355,21 +379,14 @@ int glc_mdct_forward_device(glc_ctx *ctx, const float *d_pcm, uint64_t t0, uint6
   return GLC_OK;
 }
 
-int glc_frames_from_device_records(glc_ctx *ctx, const void *d_records, uint64_t n_frames,
-                                   uint64_t n_samples, uint16_t channels, glc_frames **out) {
-  if (!ctx || !d_records || !out) return fail(ctx, GLC_EINVAL, "glc_frames_from_device_records: null argument");
-  *out = nullptr;
-  const glc_plan plan = glc::plan_encode(n_samples, channels);
-  if (plan.n_frames == 0 || plan.n_frames != n_frames)
-    return fail(ctx, GLC_EINVAL, "glc_frames_from_device_records: record count does not match the stream length");
-  const uint32_t ch = channels;
+// Queue the compaction of `n_frames` records into `d_blob` (capacity checked by the caller) on
+// the context's stream; nothing is synchronised.
+static int compact_launch(glc_ctx *ctx, const void *d_records, uint64_t n_frames, uint32_t ch, void *d_blob) {
   const uint64_t M64 = n_frames * ch;
-  if (M64 > 0xFFFFFFFFull) return fail(ctx, GLC_EINVAL, "glc_frames_from_device_records: stream too long");
+  if (M64 > 0xFFFFFFFFull) return fail(ctx, GLC_EINVAL, "compaction: frame range too long");
   const uint32_t M = static_cast<uint32_t>(M64);
-  DeviceGuard guard(ctx->device);
-  const uint8_t *recs = static_cast<const uint8_t *>(d_records);
-
-  const size_t nblk = (M + 1023) / 1024;
+  const glc::CompactLayout l = glc::compact_layout(ch, n_frames);
+  const size_t nblk = (static_cast<size_t>(M) + 1023) / 1024;
   size_t off = 0;
   auto place = [&](size_t bytes) {
     size_t at = off;
@@ -377,89 +394,60 @@ int glc_frames_from_device_records(glc_ctx *ctx, const void *d_records, uint64_t
     return at;
   };
   const size_t o_loc = place(static_cast<size_t>(M) * 4), o_blk = place(nblk * 8), o_blkr = place(nblk * 8);
-  const size_t o_tot = place(16), o_scale = place(static_cast<size_t>(M) * 4), o_raw = place(n_frames);
-  const size_t o_rowoff = place(static_cast<size_t>(M) * 8);
-  GLC_HIP(ctx, ctx->pack_meta.reserve(off));
+  const size_t o_tot = place(16);
+  GLC_HIP(ctx, ctx->pack_meta.reserve(std::max<size_t>(off, 256)));
   uint8_t *mb = static_cast<uint8_t *>(ctx->pack_meta.p);
-  auto *d_loc = reinterpret_cast<uint32_t *>(mb + o_loc);
-  auto *d_blk = reinterpret_cast<uint64_t *>(mb + o_blk);
-  auto *d_blkr = reinterpret_cast<uint64_t *>(mb + o_blkr);
-  auto *d_tot = reinterpret_cast<uint64_t *>(mb + o_tot);
-  auto *d_scale = reinterpret_cast<float *>(mb + o_scale);
-  auto *d_israw = mb + o_raw;
-  auto *d_rowoff = reinterpret_cast<uint64_t *>(mb + o_rowoff);
+  uint8_t *blob = static_cast<uint8_t *>(d_blob);
+  GLC_HIP(ctx, hipMemsetAsync(blob, 0, l.o_pairs, ctx->stream));  // header + section padding: deterministic bytes
+  GLC_HIP(ctx, glc::launch_compact(static_cast<const uint8_t *>(d_records), M, ch, n_frames,
+                                   reinterpret_cast<uint32_t *>(mb + o_loc), reinterpret_cast<uint64_t *>(mb + o_blk),
+                                   reinterpret_cast<uint64_t *>(mb + o_blkr), reinterpret_cast<uint64_t *>(mb + o_tot),
+                                   blob, l.o_israw, l.o_scale, l.o_cnt, l.o_pairs, ctx->stream));
+  return GLC_OK;
+}
 
-  GLC_HIP(ctx, glc::launch_pack_scan(recs, M, ch, d_loc, d_blk, d_blkr, d_tot, d_scale, d_israw, ctx->stream));
-  uint64_t totals[2] = {0, 0};
-  GLC_HIP(ctx, hipMemcpyAsync(totals, d_tot, 16, hipMemcpyDeviceToHost, ctx->stream));
-  GLC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // sizes are needed to size the payload buffers
-  const uint64_t n_pairs = totals[0], n_raw_rows = totals[1];
-  if (n_pairs > static_cast<uint64_t>(M) * glc::kHop || n_raw_rows > M || n_raw_rows % ch != 0)
-    return fail(ctx, GLC_EINVAL, "glc_frames_from_device_records: corrupt records");
-  GLC_HIP(ctx, ctx->pack_pairs.reserve(std::max<size_t>(n_pairs, 1) * 4));
-  GLC_HIP(ctx, ctx->pack_raw.reserve(std::max<size_t>(n_raw_rows, 1) * glc::kFrame * 2));
-  GLC_HIP(ctx, glc::launch_pack_rows(recs, M, ch, d_loc, d_blk, d_blkr, static_cast<uint32_t *>(ctx->pack_pairs.p),
-                                     d_rowoff, static_cast<int16_t *>(ctx->pack_raw.p), ctx->stream));
-
-  std::unique_ptr<glc_frames> F(new (std::nothrow) glc_frames);
-  if (!F) return fail(ctx, GLC_ENOMEM, "glc_frames_from_device_records: host allocation failed");
-  std::vector<uint64_t> row_off;
-  std::vector<float> row_scale;
-  try {
-    F->sample_rate = ctx->sample_rate;
-    F->channels = channels;
-    F->total_samples = n_samples;
-    F->encoder_delay = plan.encoder_delay;
-    F->padding = plan.padding;
-    F->original_length = n_samples;
-    F->n_frames = n_frames;
-    F->raw_tag.resize(n_frames);
-    F->pairs.resize(n_pairs);
-    F->raw.resize(n_raw_rows * glc::kFrame);
-    row_off.resize(M);
-    row_scale.resize(M);
-  } catch (const std::bad_alloc &) {
-    return fail(ctx, GLC_ENOMEM, "glc_frames_from_device_records: host allocation failed");
-  }
-  if (n_frames) GLC_HIP(ctx, hipMemcpyAsync(F->raw_tag.data(), d_israw, n_frames, hipMemcpyDeviceToHost, ctx->stream));
-  if (M) GLC_HIP(ctx, hipMemcpyAsync(row_off.data(), d_rowoff, static_cast<size_t>(M) * 8, hipMemcpyDeviceToHost, ctx->stream));
-  if (M) GLC_HIP(ctx, hipMemcpyAsync(row_scale.data(), d_scale, static_cast<size_t>(M) * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (n_pairs) GLC_HIP(ctx, hipMemcpyAsync(F->pairs.data(), ctx->pack_pairs.p, n_pairs * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (n_raw_rows) GLC_HIP(ctx, hipMemcpyAsync(F->raw.data(), ctx->pack_raw.p, n_raw_rows * glc::kFrame * 2, hipMemcpyDeviceToHost, ctx->stream));
+int glc_compact_device_records(glc_ctx *ctx, const void *d_records, uint64_t n_frames, uint16_t channels,
+                               void *d_blob, uint64_t cap, glc_compact_info *info) {
+  if (!ctx || !d_blob || !info || (!d_records && n_frames)) return fail(ctx, GLC_EINVAL, "glc_compact_device_records: null argument");
+  if (channels == 0) return fail(ctx, GLC_EINVAL, "glc_compact_device_records: channels == 0");
+  const glc::CompactLayout l = glc::compact_layout(channels, n_frames);
+  if (cap < l.bound) return fail(ctx, GLC_EINVAL, "glc_compact_device_records: blob buffer smaller than glc_compact_bound()");
+  DeviceGuard guard(ctx->device);
+  int rc = compact_launch(ctx, d_records, n_frames, channels, d_blob);
+  if (rc != GLC_OK) return rc;
+  glc::CompactHeader h;
+  GLC_HIP(ctx, hipMemcpyAsync(&h, d_blob, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
   GLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (h.magic != glc::kCompactMagic || h.bytes > l.bound)
+    return fail(ctx, GLC_EHIP, "glc_compact_device_records: the device wrote an inconsistent header");
+  info->n_frames = h.n_frames;
+  info->n_pairs = h.n_pairs;
+  info->n_raw_rows = h.n_raw_rows;
+  info->bytes = h.bytes;
+  return GLC_OK;
+}
 
-  // index vectors of EncodedAudio: raw frames have no lists / scales, compressed frames no raw_pcm
-  try {
-    F->list_begin.assign(n_frames + 1, 0);
-    F->scale_begin.assign(n_frames + 1, 0);
-    F->raw_begin.assign(n_frames + 1, 0);
-    const uint64_t n_comp_rows = static_cast<uint64_t>(M) - n_raw_rows;
-    F->list_off.clear();
-    F->list_off.reserve(n_comp_rows + 1);
-    F->scales.clear();
-    F->scales.reserve(n_comp_rows);
-    uint64_t raw_at = 0;
-    for (uint64_t f = 0; f < n_frames; ++f) {
-      if (F->raw_tag[f]) {
-        raw_at += static_cast<uint64_t>(glc::kFrame) * ch;
-      } else {
-        for (uint32_t c = 0; c < ch; ++c) {
-          F->list_off.push_back(row_off[f * ch + c]);
-          F->scales.push_back(row_scale[f * ch + c]);
-        }
-      }
-      F->list_begin[f + 1] = F->list_off.size();
-      F->scale_begin[f + 1] = F->scales.size();
-      F->raw_begin[f + 1] = raw_at;
-    }
-    F->list_off.push_back(n_pairs);
-    F->lists_canonical = true;  // ballot-packed in ascending k
-    if (raw_at != n_raw_rows * glc::kFrame)
-      return fail(ctx, GLC_EINVAL, "glc_frames_from_device_records: raw flag / raw row mismatch");
-  } catch (const std::bad_alloc &) {
-    return fail(ctx, GLC_ENOMEM, "glc_frames_from_device_records: host allocation failed");
-  }
-  *out = F.release();
+int glc_frames_from_device_records(glc_ctx *ctx, const void *d_records, uint64_t n_frames,
+                                   uint64_t n_samples, uint16_t channels, glc_frames **out) {
+  if (!ctx || !d_records || !out) return fail(ctx, GLC_EINVAL, "glc_frames_from_device_records: null argument");
+  *out = nullptr;
+  const glc_plan plan = glc::plan_encode(n_samples, channels);
+  if (plan.n_frames == 0 || plan.n_frames != n_frames)
+    return fail(ctx, GLC_EINVAL, "glc_frames_from_device_records: record count does not match the stream length");
+  DeviceGuard guard(ctx->device);
+  const glc::CompactLayout l = glc::compact_layout(channels, n_frames);
+  GLC_HIP(ctx, ctx->pack_blob.reserve(l.bound));
+  glc_compact_info info;
+  int rc = glc_compact_device_records(ctx, d_records, n_frames, channels, ctx->pack_blob.p, ctx->pack_blob.cap, &info);
+  if (rc != GLC_OK) return rc;
+  // only the bitstream's payload crosses PCIe, through pinned memory
+  GLC_HIP(ctx, ctx->host_stage.reserve(info.bytes));
+  GLC_HIP(ctx, hipMemcpyAsync(ctx->host_stage.p, ctx->pack_blob.p, info.bytes, hipMemcpyDeviceToHost, ctx->stream));
+  GLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const void *blobs[1] = {ctx->host_stage.p};
+  const uint64_t sizes[1] = {info.bytes};
+  rc = glc::frames_from_compact(ctx->sample_rate, n_samples, channels, blobs, sizes, 1, /*trusted=*/true, out);
+  if (rc != GLC_OK) return fail(ctx, rc, std::string("glc_frames_from_device_records: ") + glc_last_error(nullptr));
   return GLC_OK;
 }
 
@@ -539,6 +527,13 @@ int decode_prepare_impl(glc_ctx *ctx, const glc_frames *in) {
   const uint64_t nf = in->n_frames;
   const uint64_t M = nf * ch;
   if (M > 0xFFFFFFFFull) return fail(ctx, GLC_EINVAL, "glc_decode: stream too long");
+  // The sparse rows of this stream are still on the device from an earlier call (a glc_frames is
+  // immutable and its uid is unique in the process): nothing to prepare or upload.
+  if (ctx->dec_uid != 0 && ctx->dec_uid == in->uid) {
+    ctx->dec_next = 0;
+    return GLC_OK;
+  }
+  ctx->dec_uid = 0;
 
   std::vector<uint64_t> row_begin(M, 0), row_raw_len(M, 0);
   std::vector<uint32_t> row_cnt(M, 0);
@@ -584,9 +579,10 @@ int decode_prepare_impl(glc_ctx *ctx, const glc_frames *in) {
           if (k < glc::kHop) dense[k] = static_cast<int16_t>(in->pairs[j] >> 16);
         }
         row_begin[m] = n_stored + extra.size();
-        // a stored q == 0 dequantises to +/-0.0 and contributes nothing to the running sum
+        // stored zeros stay: 0 * scale is NaN when the scale is infinite (src/codec.rs:663), and
+        // the result must not depend on whether the list happened to be in canonical order
         for (uint32_t k = 0; k < glc::kHop; ++k)
-          if (dense[k] != INT32_MIN && dense[k] != 0)
+          if (dense[k] != INT32_MIN)
             extra.push_back(k | (static_cast<uint32_t>(static_cast<uint16_t>(dense[k])) << 16));
         row_cnt[m] = static_cast<uint32_t>(n_stored + extra.size() - row_begin[m]);
       }
@@ -634,6 +630,7 @@ int decode_prepare_impl(glc_ctx *ctx, const glc_frames *in) {
   ctx->dec_ch = ch;
   ctx->dec_frames = nf;
   ctx->dec_next = 0;
+  ctx->dec_uid = in->uid;
   return GLC_OK;
 }
 
@@ -805,6 +802,21 @@ int glc_decode_range_device(glc_ctx *ctx, const glc_frames *in, uint64_t hop_beg
   int rc = decode_prepare(ctx, in);
   if (rc != GLC_OK) return rc;
   return decode_hops_prepared(ctx, hop_begin, hop_end, d_out);
+}
+
+int glc_imdct_device(glc_ctx *ctx, const glc_frames *in, uint64_t frame_begin, uint64_t frame_end,
+                     float *d_blocks) {
+  if (!ctx || !in || !d_blocks) return fail(ctx, GLC_EINVAL, "glc_imdct_device: null argument");
+  ctx->stream_open = false;
+  if (frame_begin > frame_end || frame_end > in->n_frames)
+    return fail(ctx, GLC_EINVAL, "glc_imdct_device: frame range out of bounds");
+  int rc = decode_prepare(ctx, in);
+  if (rc != GLC_OK) return rc;
+  DeviceGuard guard(ctx->device);
+  const uint32_t ch = ctx->dec_ch;
+  GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, static_cast<uint32_t>(frame_begin * ch),
+                                      static_cast<uint32_t>((frame_end - frame_begin) * ch), ch, d_blocks, ctx->stream));
+  return GLC_OK;
 }
 
 int glc_decode_stream_begin(glc_ctx *ctx, const glc_frames *in) {

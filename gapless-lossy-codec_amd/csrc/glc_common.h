@@ -48,9 +48,54 @@ inline uint64_t record_bytes(uint32_t ch) {
   return record_header_bytes(ch) + 2ull * kFrame * ch;
 }
 
+// Compact ("bitstream payload") form of a contiguous frame range, one self-describing blob:
+//   header (64 B) | is_raw u8[n_frames] | scale f32[M] | cnt u32[M] | pairs u32[n_pairs] |
+//   raw i16[n_raw_rows][2048]          M = n_frames * channels, every section 64-byte aligned
+// cnt[m] is the sparse-list length of row m (0 for the rows of raw frames); pairs are the lists
+// back to back in row order, (u16 idx | i16 q << 16) ascending in idx; raw holds the 2048-sample
+// planes of the rows of raw frames in row order (channel-planar per frame, quirk Q1).  This is what
+// crosses PCIe after an encode and what a multi-GPU job gathers: ~1/8 of the fixed-size records.
+constexpr uint32_t kCompactMagic = 0x42434C47u;  // "GLCB"
+struct CompactHeader {
+  uint32_t magic;
+  uint32_t channels;
+  uint64_t n_frames;
+  uint64_t n_pairs;
+  uint64_t n_raw_rows;
+  uint64_t bytes;  // whole blob, header included
+  uint64_t reserved[3];
+};
+static_assert(sizeof(CompactHeader) == 64, "compact header is 64 bytes");
+inline uint64_t align64(uint64_t v) { return (v + 63ull) & ~63ull; }
+struct CompactLayout {
+  uint64_t o_israw, o_scale, o_cnt, o_pairs;  // byte offsets of the fixed sections
+  uint64_t bound;                             // worst-case blob size for this range
+};
+inline CompactLayout compact_layout(uint32_t ch, uint64_t n_frames) {
+  const uint64_t M = n_frames * ch;
+  CompactLayout l;
+  l.o_israw = sizeof(CompactHeader);
+  l.o_scale = l.o_israw + align64(n_frames);
+  l.o_cnt = l.o_scale + align64(4 * M);
+  l.o_pairs = l.o_cnt + align64(4 * M);
+  // a row is either compressed (<= 1024 pairs = 4096 B) or raw (2048 i16 = 4096 B)
+  l.bound = l.o_pairs + 4096ull * M + 64ull;
+  return l;
+}
+inline uint64_t compact_raw_offset(const CompactLayout &l, uint64_t n_pairs) { return align64(l.o_pairs + 4 * n_pairs); }
+
 void set_global_error(const std::string &msg);
 
+// Host assembly of EncodedAudio from compact blobs in frame order (glc_frames_from_compact).
+// `trusted`: the blobs were produced by this process's own pack kernels (lists known canonical).
+int frames_from_compact(uint32_t sample_rate, uint64_t n_samples, uint16_t channels, const void *const *blobs,
+                        const uint64_t *blob_bytes, uint32_t n_blobs, bool trusted, glc_frames **out);
+
 }  // namespace glc
+
+namespace glc {
+uint64_t next_frames_uid();  // never 0
+}
 
 // EncodedAudio (src/codec.rs:31-69) in a flat, general form: every Vec of the schema keeps its
 // own length so that any well-formed bincode stream round-trips byte-for-byte.
@@ -75,4 +120,7 @@ struct glc_frames {
   // true when every sparse list is known to be strictly ascending with idx < 1024 (streams
   // assembled from this library's own records); streams read from bytes are checked at decode
   bool lists_canonical = false;
+  // process-unique identity of this (immutable) object: lets a context recognise a stream whose
+  // sparse rows it already holds on the device (glc_decode_* called again on the same frames)
+  uint64_t uid = glc::next_frames_uid();
 };

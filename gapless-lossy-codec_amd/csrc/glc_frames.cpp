@@ -9,6 +9,7 @@
 //     u64 n_scales, n_scales x f32
 //     u8 tag, if tag == 1: u64 n_raw, n_raw x i16
 //   u32 encoder_delay | u32 padding | u64 original_length
+#include <atomic>
 #include <cstdio>
 #include <memory>
 #include <new>
@@ -57,7 +58,222 @@ struct Reader {
 
 }  // namespace
 
+namespace glc {
+
+uint64_t next_frames_uid() {
+  static std::atomic<uint64_t> counter{0};
+  return counter.fetch_add(1, std::memory_order_relaxed) + 1;
+}
+
+int frames_from_compact(uint32_t sample_rate, uint64_t n_samples, uint16_t channels, const void *const *blobs,
+                        const uint64_t *blob_bytes, uint32_t n_blobs, bool trusted, glc_frames **out) {
+  if (!out || (n_blobs && (!blobs || !blob_bytes))) return GLC_EINVAL;
+  *out = nullptr;
+  const glc_plan plan = plan_encode(n_samples, channels);
+  if (plan.n_frames == 0) {
+    set_global_error("glc_frames_from_compact: the reference encoder panics on this stream length");
+    return GLC_EINVAL;
+  }
+  const uint32_t ch = channels;
+  // pass 1: validate every blob against its own header and the stream
+  uint64_t n_frames = 0, n_pairs = 0, n_raw_rows = 0;
+  std::vector<CompactHeader> hdrs(n_blobs);
+  for (uint32_t b = 0; b < n_blobs; ++b) {
+    if (!blobs[b] || blob_bytes[b] < sizeof(CompactHeader)) {
+      set_global_error("glc_frames_from_compact: blob shorter than its header");
+      return GLC_EFORMAT;
+    }
+    CompactHeader &h = hdrs[b];
+    std::memcpy(&h, blobs[b], sizeof h);
+    if (h.magic != kCompactMagic || h.channels != ch || h.n_frames > plan.n_frames) {
+      set_global_error("glc_frames_from_compact: bad magic, channel count or frame count");
+      return GLC_EFORMAT;
+    }
+    const CompactLayout l = compact_layout(ch, h.n_frames);
+    const uint64_t M = h.n_frames * ch;
+    if (h.n_pairs > M * kHop || h.n_raw_rows > M || h.n_raw_rows % ch != 0) {
+      set_global_error("glc_frames_from_compact: corrupt blob (pair / raw-row counts)");
+      return GLC_EFORMAT;
+    }
+    const uint64_t need = compact_raw_offset(l, h.n_pairs) + h.n_raw_rows * kFrame * 2;
+    if (h.bytes != need || blob_bytes[b] < need) {
+      set_global_error("glc_frames_from_compact: blob size does not match its header");
+      return GLC_EFORMAT;
+    }
+    n_frames += h.n_frames;
+    n_pairs += h.n_pairs;
+    n_raw_rows += h.n_raw_rows;
+  }
+  if (n_frames != plan.n_frames) {
+    set_global_error("glc_frames_from_compact: the blobs do not add up to the stream's frame count");
+    return GLC_EINVAL;
+  }
+  std::unique_ptr<glc_frames> F(new (std::nothrow) glc_frames);
+  if (!F) return GLC_ENOMEM;
+  F->sample_rate = sample_rate;
+  F->channels = channels;
+  F->total_samples = n_samples;           // src/codec.rs:423,555
+  F->encoder_delay = plan.encoder_delay;  // :547
+  F->padding = plan.padding;              // :546
+  F->original_length = n_samples;         // :562
+  F->n_frames = n_frames;
+  bool canonical = true;
+  try {
+    F->list_begin.assign(n_frames + 1, 0);
+    F->scale_begin.assign(n_frames + 1, 0);
+    F->raw_begin.assign(n_frames + 1, 0);
+    F->raw_tag.resize(n_frames);
+    F->pairs.resize(n_pairs);
+    F->raw.resize(n_raw_rows * kFrame);
+    const uint64_t n_comp_rows = n_frames * ch - n_raw_rows;
+    F->list_off.clear();
+    F->list_off.reserve(n_comp_rows + 1);
+    F->scales.clear();
+    F->scales.reserve(n_comp_rows);
+    uint64_t f_at = 0, p_at = 0, r_at = 0;  // frames / pairs / raw samples placed so far
+    for (uint32_t b = 0; b < n_blobs; ++b) {
+      const CompactHeader &h = hdrs[b];
+      const CompactLayout l = compact_layout(ch, h.n_frames);
+      const uint8_t *base = static_cast<const uint8_t *>(blobs[b]);
+      const uint8_t *israw = base + l.o_israw;
+      const float *scale = reinterpret_cast<const float *>(base + l.o_scale);
+      const uint32_t *cnt = reinterpret_cast<const uint32_t *>(base + l.o_cnt);
+      const uint32_t *pairs = reinterpret_cast<const uint32_t *>(base + l.o_pairs);
+      const int16_t *raw = reinterpret_cast<const int16_t *>(base + compact_raw_offset(l, h.n_pairs));
+      if (h.n_pairs) std::memcpy(F->pairs.data() + p_at, pairs, h.n_pairs * 4);
+      if (h.n_raw_rows) std::memcpy(F->raw.data() + r_at, raw, h.n_raw_rows * kFrame * 2);
+      uint64_t p_in = 0, raw_rows_in = 0;
+      for (uint64_t f = 0; f < h.n_frames; ++f) {
+        const uint64_t fo = f_at + f;
+        F->raw_tag[fo] = israw[f] ? 1 : 0;
+        if (israw[f]) {
+          raw_rows_in += ch;
+          for (uint32_t c = 0; c < ch; ++c)
+            if (cnt[f * ch + c] != 0) {
+              set_global_error("glc_frames_from_compact: raw frame with a sparse list");
+              return GLC_EFORMAT;
+            }
+        } else {
+          for (uint32_t c = 0; c < ch; ++c) {
+            const uint32_t n = cnt[f * ch + c];
+            if (n > kHop || p_in + n > h.n_pairs) {
+              set_global_error("glc_frames_from_compact: corrupt blob (row counts exceed the pair pool)");
+              return GLC_EFORMAT;
+            }
+            if (!trusted && canonical) {
+              int32_t last = -1;
+              for (uint32_t j = 0; j < n; ++j) {
+                const int32_t k = static_cast<int32_t>(pairs[p_in + j] & 0xFFFFu);
+                if (k <= last || k >= static_cast<int32_t>(kHop)) {
+                  canonical = false;
+                  break;
+                }
+                last = k;
+              }
+            }
+            F->list_off.push_back(p_at + p_in);
+            F->scales.push_back(scale[f * ch + c]);
+            p_in += n;
+          }
+        }
+        F->list_begin[fo + 1] = F->list_off.size();
+        F->scale_begin[fo + 1] = F->scales.size();
+        F->raw_begin[fo + 1] = r_at + raw_rows_in * kFrame;
+      }
+      if (p_in != h.n_pairs || raw_rows_in != h.n_raw_rows) {
+        set_global_error("glc_frames_from_compact: corrupt blob (section totals disagree with the header)");
+        return GLC_EFORMAT;
+      }
+      f_at += h.n_frames;
+      p_at += h.n_pairs;
+      r_at += h.n_raw_rows * kFrame;
+    }
+    F->list_off.push_back(n_pairs);
+  } catch (const std::bad_alloc &) {
+    return GLC_ENOMEM;
+  }
+  F->lists_canonical = canonical;
+  *out = F.release();
+  return GLC_OK;
+}
+
+}  // namespace glc
+
 extern "C" {
+
+uint64_t glc_compact_bound(uint16_t channels, uint64_t n_frames) {
+  return glc::compact_layout(channels, n_frames).bound;
+}
+
+int glc_compact_records(const void *records, uint64_t n_frames, uint16_t channels, void *blob, uint64_t cap,
+                        glc_compact_info *info) {
+  if (!blob || !info || channels == 0 || (!records && n_frames)) return GLC_EINVAL;
+  const uint32_t ch = channels;
+  const glc::CompactLayout l = glc::compact_layout(ch, n_frames);
+  if (cap < l.bound) {
+    glc::set_global_error("glc_compact_records: blob buffer smaller than glc_compact_bound()");
+    return GLC_EINVAL;
+  }
+  const uint64_t rec = glc::record_bytes(ch), hdr = glc::record_header_bytes(ch);
+  uint8_t *out = static_cast<uint8_t *>(blob);
+  std::memset(out, 0, l.o_pairs);
+  uint8_t *israw = out + l.o_israw;
+  float *scale = reinterpret_cast<float *>(out + l.o_scale);
+  uint32_t *cnt = reinterpret_cast<uint32_t *>(out + l.o_cnt);
+  uint32_t *pairs = reinterpret_cast<uint32_t *>(out + l.o_pairs);
+  const uint8_t *base = static_cast<const uint8_t *>(records);
+  uint64_t n_pairs = 0, n_raw_rows = 0;
+  for (uint64_t f = 0; f < n_frames; ++f) {
+    const uint8_t *r = base + f * rec;
+    uint32_t raw;
+    std::memcpy(&raw, r, 4);
+    israw[f] = raw ? 1 : 0;
+    for (uint32_t c = 0; c < ch; ++c) {
+      uint32_t nnz;
+      std::memcpy(&scale[f * ch + c], r + 8 + 8 * c, 4);
+      std::memcpy(&nnz, r + 8 + 8 * c + 4, 4);
+      if (nnz > glc::kHop) nnz = glc::kHop;
+      cnt[f * ch + c] = raw ? 0 : nnz;
+      if (raw) {
+        ++n_raw_rows;
+        continue;
+      }
+      const int16_t *row = reinterpret_cast<const int16_t *>(r + hdr) + static_cast<size_t>(c) * glc::kFrame;
+      uint32_t done = 0;
+      for (uint32_t k = 0; k < glc::kHop && done < nnz; ++k)
+        if (row[k] != 0) pairs[n_pairs + done++] = k | (static_cast<uint32_t>(static_cast<uint16_t>(row[k])) << 16);
+      for (; done < nnz; ++done) pairs[n_pairs + done] = 0xFFFFu;  // same filler as the device kernel
+      n_pairs += nnz;
+    }
+  }
+  const uint64_t raw_off = glc::compact_raw_offset(l, n_pairs);
+  std::memset(out + l.o_pairs + 4 * n_pairs, 0, raw_off - (l.o_pairs + 4 * n_pairs));
+  int16_t *rawp = reinterpret_cast<int16_t *>(out + raw_off);
+  uint64_t rr = 0;
+  for (uint64_t f = 0; f < n_frames; ++f) {
+    if (!israw[f]) continue;
+    std::memcpy(rawp + rr * glc::kFrame, base + f * rec + hdr, sizeof(int16_t) * glc::kFrame * ch);
+    rr += ch;
+  }
+  glc::CompactHeader h{};
+  h.magic = glc::kCompactMagic;
+  h.channels = ch;
+  h.n_frames = n_frames;
+  h.n_pairs = n_pairs;
+  h.n_raw_rows = n_raw_rows;
+  h.bytes = raw_off + n_raw_rows * glc::kFrame * 2;
+  std::memcpy(out, &h, sizeof h);
+  info->n_frames = n_frames;
+  info->n_pairs = n_pairs;
+  info->n_raw_rows = n_raw_rows;
+  info->bytes = h.bytes;
+  return GLC_OK;
+}
+
+int glc_frames_from_compact(uint32_t sample_rate, uint64_t n_samples, uint16_t channels, const void *const *blobs,
+                            const uint64_t *blob_bytes, uint32_t n_blobs, glc_frames **out) {
+  return glc::frames_from_compact(sample_rate, n_samples, channels, blobs, blob_bytes, n_blobs, false, out);
+}
 
 uint64_t glc_record_bytes(uint16_t channels) { return glc::record_bytes(channels); }
 

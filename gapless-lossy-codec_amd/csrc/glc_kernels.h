@@ -39,16 +39,14 @@ hipError_t launch_quantize(const DeviceTables &t, const float *coef, uint32_t M,
 hipError_t launch_decide_raw(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin,
                              uint32_t n_frames, uint8_t *records, hipStream_t s);
 
-// P1+P2: offsets of the compact (bitstream) form.  loc[M]: in-block offsets (low 21 bits pairs,
-// high 11 bits rows of raw frames); blk[] / blk_raw[]: block offsets (exclusive after the call);
-// totals[0] = pairs, totals[1] = raw rows; compact scales[M] and is_raw[frames].
-hipError_t launch_pack_scan(const uint8_t *records, uint32_t M, uint32_t ch, uint32_t *loc, uint64_t *blk,
-                            uint64_t *blk_raw, uint64_t *totals, float *scales, uint8_t *is_raw, hipStream_t s);
-// P3: ascending (u16 idx | i16 q << 16) pairs of every compressed row at pairs[row_off[m]]; the
-// 2048-sample planes of raw-frame rows go to raw_pool in row order.
-hipError_t launch_pack_rows(const uint8_t *records, uint32_t M, uint32_t ch, const uint32_t *loc,
-                            const uint64_t *blk, const uint64_t *blk_raw, uint32_t *pairs, uint64_t *row_off,
-                            int16_t *raw_pool, hipStream_t s);
+// P1-P4: compact blob (glc_common.h CompactLayout) of M = n_frames*ch rows of records, written to
+// `blob` on the device: header, per-frame raw flags, per-row scale and pair count, the ascending
+// (u16 idx | i16 q << 16) pairs of every compressed row back to back, then the 2048-sample planes of
+// raw-frame rows.  loc[M], blk[ceil(M/1024)], blk_raw[same], totals[2] are scratch.  The alignment
+// padding of the fixed sections is NOT written here (the caller zeroes [0, o_pairs) first).
+hipError_t launch_compact(const uint8_t *records, uint32_t M, uint32_t ch, uint64_t n_frames, uint32_t *loc,
+                          uint64_t *blk, uint64_t *blk_raw, uint64_t *totals, uint8_t *blob, uint64_t o_israw,
+                          uint64_t o_scale, uint64_t o_cnt, uint64_t o_pairs, hipStream_t s);
 
 // D1: sparse dequant + inverse MDCT + window -> blocks[row][2048].
 //   pairs: packed (u16 idx | i16 q << 16), canonical (ascending, unique, idx < 1024)

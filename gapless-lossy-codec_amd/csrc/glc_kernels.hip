@@ -471,19 +471,22 @@ __global__ __launch_bounds__(256) void k_overlap_add(const float *__restrict__ b
 }
 
 // ------------------------------------------------------------------------------------------
-// P1-P3: device-side compaction of frame records into the bitstream's sparse form, so that the
-// host boundary (and a gather) moves (u16 idx, i16 q) pairs instead of dense 1024-bin rows.
+// P1-P4: device-side compaction of frame records into the compact blob (glc_common.h
+// CompactLayout), so that the host boundary and the multi-GPU gather move (u16 idx, i16 q) pairs
+// instead of dense 1024-bin rows.
 //   P1  per row: pairs it contributes (nnz, 0 for rows of raw frames); exclusive scan inside
-//       blocks of 1024 rows; compact per-row scale and per-frame raw flag
+//       blocks of 1024 rows; per-row scale and count, per-frame raw flag into the blob
 //   P2  exclusive scan of the block totals (one workgroup)
-//   P3  one wave per row: ballot + popcount prefix keeps ascending k (src/codec.rs:303-306)
+//   P3  blob header (needs the totals), zeroes the alignment gap in front of the raw section
+//   P4  one wave per row: ballot + popcount prefix keeps ascending k (src/codec.rs:303-306);
+//       planes of raw-frame rows go to the raw section, which starts behind the pairs
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pack_scan_rows(const unsigned char *__restrict__ records, unsigned M,
                                                          unsigned ch, unsigned long long rec_bytes,
                                                          unsigned *__restrict__ loc,
                                                          unsigned long long *__restrict__ blk,
                                                          unsigned long long *__restrict__ blk_raw,
-                                                         float *__restrict__ scales,
+                                                         float *__restrict__ scales, unsigned *__restrict__ cnt,
                                                          unsigned char *__restrict__ is_raw) {
   // one 32-bit word scans both counts: low 21 bits = pairs (<= 1024*1024 per block), high 11 =
   // rows of raw frames (<= 1024 per block)
@@ -498,8 +501,10 @@ __global__ __launch_bounds__(256) void k_pack_scan_rows(const unsigned char *__r
       const unsigned frame = m / ch, c = m % ch;
       const unsigned char *rec = records + static_cast<size_t>(frame) * rec_bytes;
       const unsigned raw = *reinterpret_cast<const unsigned *>(rec);
-      n = raw ? (1u << 21) : *reinterpret_cast<const unsigned *>(rec + 8 + 8 * c + 4);
+      const unsigned nnz = min(*reinterpret_cast<const unsigned *>(rec + 8 + 8 * c + 4), static_cast<unsigned>(kHopI));
+      n = raw ? (1u << 21) : nnz;
       scales[m] = *reinterpret_cast<const float *>(rec + 8 + 8 * c);
+      cnt[m] = raw ? 0u : nnz;
       if (c == 0) is_raw[frame] = raw ? 1 : 0;
     }
     v[j] = sum;  // exclusive within the thread
@@ -546,42 +551,65 @@ __global__ __launch_bounds__(1024) void k_pack_scan_blocks(unsigned long long *_
   if (threadIdx.x == 0) *total = carry;
 }
 
+__global__ __launch_bounds__(64) void k_pack_header(const unsigned long long *__restrict__ totals, unsigned ch,
+                                                     unsigned long long n_frames, unsigned long long o_pairs,
+                                                     unsigned char *__restrict__ blob) {
+  const unsigned long long n_pairs = totals[0], n_raw_rows = totals[1];
+  const unsigned long long pairs_end = o_pairs + 4ull * n_pairs;
+  const unsigned long long raw_off = (pairs_end + 63ull) & ~63ull;
+  if (threadIdx.x == 0) {
+    unsigned long long *h = reinterpret_cast<unsigned long long *>(blob);
+    h[0] = 0x42434C47ull | (static_cast<unsigned long long>(ch) << 32);  // magic, channels
+    h[1] = n_frames;
+    h[2] = n_pairs;
+    h[3] = n_raw_rows;
+    h[4] = raw_off + n_raw_rows * 4096ull;
+    h[5] = h[6] = h[7] = 0ull;
+  }
+  if (pairs_end + threadIdx.x < raw_off) blob[pairs_end + threadIdx.x] = 0;  // deterministic padding
+}
+
 __global__ __launch_bounds__(256) void k_pack_rows(const unsigned char *__restrict__ records, unsigned M,
                                                     unsigned ch, unsigned long long rec_bytes,
                                                     unsigned long long hdr_bytes, const unsigned *__restrict__ loc,
                                                     const unsigned long long *__restrict__ blk,
                                                     const unsigned long long *__restrict__ blk_raw,
-                                                    unsigned *__restrict__ pairs,
-                                                    unsigned long long *__restrict__ row_off,
-                                                    short *__restrict__ raw_pool) {
+                                                    const unsigned long long *__restrict__ totals,
+                                                    const unsigned *__restrict__ cnt, unsigned long long o_pairs,
+                                                    unsigned char *__restrict__ blob) {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const unsigned m = blockIdx.x * 4 + w;
   if (m >= M) return;
   const unsigned l = loc[m];
   const unsigned long long off = blk[m >> 10] + (l & 0x1FFFFFu);
-  if (lane == 0) row_off[m] = off;
   const unsigned frame = m / ch, c = m % ch;
   const unsigned char *rec = records + static_cast<size_t>(frame) * rec_bytes;
   const short *qrow = reinterpret_cast<const short *>(rec + hdr_bytes) + static_cast<size_t>(c) * kFrameI;
   if (*reinterpret_cast<const unsigned *>(rec)) {
-    // row of a raw frame: its 2048-sample plane goes to the raw pool (planar order == row order, Q1)
+    // row of a raw frame: its 2048-sample plane goes to the raw section (planar order == row order, Q1)
+    const unsigned long long raw_off = (o_pairs + 4ull * totals[0] + 63ull) & ~63ull;
     const unsigned long long rrow = blk_raw[m >> 10] + (l >> 21);
     const short4 *src = reinterpret_cast<const short4 *>(qrow);
-    short4 *dst = reinterpret_cast<short4 *>(raw_pool + rrow * kFrameI);
+    short4 *dst = reinterpret_cast<short4 *>(blob + raw_off + rrow * (kFrameI * 2ull));
     for (int i = lane; i < kFrameI / 4; i += 64) dst[i] = src[i];
     return;
   }
-  unsigned *dst = pairs + off;
+  unsigned *dst = reinterpret_cast<unsigned *>(blob + o_pairs) + off;
+  const unsigned room = cnt[m];  // a record whose nnz field disagrees with its row cannot write past its slot
   unsigned done = 0;
   for (int k0 = 0; k0 < kHopI; k0 += 64) {
     const short q = qrow[k0 + lane];
     const unsigned long long mask = __ballot(q != 0);
     if (q != 0) {
       const unsigned pos = done + __popcll(mask & ((1ull << lane) - 1ull));
-      dst[pos] = static_cast<unsigned>(k0 + lane) | (static_cast<unsigned>(static_cast<unsigned short>(q)) << 16);
+      if (pos < room)
+        dst[pos] = static_cast<unsigned>(k0 + lane) | (static_cast<unsigned>(static_cast<unsigned short>(q)) << 16);
     }
     done += __popcll(mask);
   }
+  // fewer non-zeros than the nnz field claims: fill the rest of the slot (idx 0xFFFF is ignored by
+  // every reader, src/codec.rs:660) so the blob never carries uninitialised bytes
+  for (unsigned pos = done + lane; pos < room; pos += 64) dst[pos] = 0xFFFFu;
 }
 
 }  // namespace
@@ -632,31 +660,30 @@ hipError_t launch_decide_raw(const DeviceTables &t, const PcmView &pcm, uint64_t
   return hipGetLastError();
 }
 
-hipError_t launch_pack_scan(const uint8_t *records, uint32_t M, uint32_t ch, uint32_t *loc, uint64_t *blk,
-                            uint64_t *blk_raw, uint64_t *totals, float *scales, uint8_t *is_raw, hipStream_t s) {
-  if (M == 0) return hipMemsetAsync(totals, 0, 2 * sizeof(uint64_t), s);
+hipError_t launch_compact(const uint8_t *records, uint32_t M, uint32_t ch, uint64_t n_frames, uint32_t *loc,
+                          uint64_t *blk, uint64_t *blk_raw, uint64_t *totals, uint8_t *blob, uint64_t o_israw,
+                          uint64_t o_scale, uint64_t o_cnt, uint64_t o_pairs, hipStream_t s) {
+  auto *t = reinterpret_cast<unsigned long long *>(totals);
+  if (M == 0) {
+    hipError_t e = hipMemsetAsync(totals, 0, 2 * sizeof(uint64_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_pack_header, dim3(1), dim3(64), 0, s, t, ch, 0ull, o_pairs, blob);
+    return hipGetLastError();
+  }
   const unsigned long long hdr = ((8ull + 8ull * ch) + 15ull) & ~15ull;
   const unsigned long long rec = hdr + 2ull * kFrameI * ch;
   const unsigned nblk = (M + 1023) / 1024;
   auto *b = reinterpret_cast<unsigned long long *>(blk);
   auto *br = reinterpret_cast<unsigned long long *>(blk_raw);
-  auto *t = reinterpret_cast<unsigned long long *>(totals);
-  hipLaunchKernelGGL(k_pack_scan_rows, dim3(nblk), dim3(256), 0, s, records, M, ch, rec, loc, b, br, scales, is_raw);
+  hipLaunchKernelGGL(k_pack_scan_rows, dim3(nblk), dim3(256), 0, s, records, M, ch, rec, loc, b, br,
+                     reinterpret_cast<float *>(blob + o_scale), reinterpret_cast<unsigned *>(blob + o_cnt),
+                     blob + o_israw);
   hipLaunchKernelGGL(k_pack_scan_blocks, dim3(1), dim3(1024), 0, s, b, nblk, t);
   hipLaunchKernelGGL(k_pack_scan_blocks, dim3(1), dim3(1024), 0, s, br, nblk, t + 1);
-  return hipGetLastError();
-}
-
-hipError_t launch_pack_rows(const uint8_t *records, uint32_t M, uint32_t ch, const uint32_t *loc,
-                            const uint64_t *blk, const uint64_t *blk_raw, uint32_t *pairs, uint64_t *row_off,
-                            int16_t *raw_pool, hipStream_t s) {
-  if (M == 0) return hipSuccess;
-  const unsigned long long hdr = ((8ull + 8ull * ch) + 15ull) & ~15ull;
-  const unsigned long long rec = hdr + 2ull * kFrameI * ch;
-  hipLaunchKernelGGL(k_pack_rows, dim3((M + 3) / 4), dim3(256), 0, s, records, M, ch, rec, hdr, loc,
-                     reinterpret_cast<const unsigned long long *>(blk),
-                     reinterpret_cast<const unsigned long long *>(blk_raw), pairs,
-                     reinterpret_cast<unsigned long long *>(row_off), raw_pool);
+  hipLaunchKernelGGL(k_pack_header, dim3(1), dim3(64), 0, s, t, ch, static_cast<unsigned long long>(n_frames),
+                     static_cast<unsigned long long>(o_pairs), blob);
+  hipLaunchKernelGGL(k_pack_rows, dim3((M + 3) / 4), dim3(256), 0, s, records, M, ch, rec, hdr, loc, b, br, t,
+                     reinterpret_cast<const unsigned *>(blob + o_cnt), static_cast<unsigned long long>(o_pairs), blob);
   return hipGetLastError();
 }
 

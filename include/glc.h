@@ -143,6 +143,36 @@ int glc_frames_from_records(uint32_t sample_rate, uint64_t n_samples, uint16_t c
 int glc_frames_from_device_records(glc_ctx *ctx, const void *d_records, uint64_t n_frames,
                                    uint64_t n_samples, uint16_t channels, glc_frames **out);
 
+/* Compact form of a contiguous frame range: one self-describing blob holding exactly the
+ * bitstream's payload for those frames (per-frame raw flags, per-row scale factor and list length,
+ * the (u16 index, i16 value) lists of src/codec.rs:303-306 back to back, raw_pcm planes of raw
+ * frames) - about 1/8 of the fixed-size records on tonal material.  It is what crosses PCIe after an
+ * encode and what a multi-GPU job gathers to its root: every rank compacts its own frame
+ * range, the blobs travel (RCCL send/recv or gather, sizes from glc_compact_info.bytes), and the root
+ * assembles EncodedAudio from the blobs in frame order.  Layout: DESIGN.md section 3. */
+typedef struct glc_compact_info {
+  uint64_t n_frames;
+  uint64_t n_pairs;    /* total sparse-list entries */
+  uint64_t n_raw_rows; /* frame-channels that belong to raw frames */
+  uint64_t bytes;      /* size of the blob (what has to travel) */
+} glc_compact_info;
+/* Capacity a blob buffer needs for any `n_frames` frames of `channels` channels (worst case). */
+uint64_t glc_compact_bound(uint16_t channels, uint64_t n_frames);
+/* Device-side compaction (scan + ballot pack, ascending k) of `n_frames` records at d_records into
+ * the device buffer d_blob (cap >= glc_compact_bound).  Runs on the context's stream and
+ * synchronises it (the sizes come back through `info`).  n_frames may be 0 (an empty shard). */
+int glc_compact_device_records(glc_ctx *ctx, const void *d_records, uint64_t n_frames, uint16_t channels,
+                               void *d_blob, uint64_t cap, glc_compact_info *info);
+/* Host twin of the same packing, for records that are already in host memory. */
+int glc_compact_records(const void *records, uint64_t n_frames, uint16_t channels, void *blob, uint64_t cap,
+                        glc_compact_info *info);
+/* Host assembly of EncodedAudio (header + gapless info as src/codec.rs:543-564) from `n_blobs`
+ * host-resident blobs that together cover the stream's frames in order.  Every count in a blob is
+ * validated against its size; GLC_EFORMAT on inconsistency. */
+int glc_frames_from_compact(uint32_t sample_rate, uint64_t n_samples, uint16_t channels,
+                            const void *const *blobs, const uint64_t *blob_bytes, uint32_t n_blobs,
+                            glc_frames **out);
+
 /* ---- decode --------------------------------------------------------------------------- */
 
 /* Length Decoder::decode will return: min(original_length, (n_frames+1)*1024*ch - delay). */
@@ -157,7 +187,9 @@ int glc_decode(glc_ctx *ctx, const glc_frames *in, float *pcm_out, uint64_t cap,
  * 1024 * channels samples, src/codec.rs:688-732) is written to the device buffer d_all (capacity
  * cap_all samples); *start / *n_out give the gapless-trimmed window Decoder::decode would return
  * (:756-765) inside it.  Work is queued on glc_ctx_stream(ctx) and NOT synchronised, except for
- * the one-off upload of the sparse rows. */
+ * the one-off upload of the sparse rows: a context keeps the rows of the last stream it decoded on
+ * the device, so decoding the same glc_frames object again (any glc_decode_* entry point) uploads
+ * nothing. */
 int glc_decode_device(glc_ctx *ctx, const glc_frames *in, float *d_all, uint64_t cap_all,
                       uint64_t *start, uint64_t *n_out);
 
@@ -169,6 +201,14 @@ int glc_decode_device(glc_ctx *ctx, const glc_frames *in, float *d_all, uint64_t
  * GPUs concatenate to exactly the whole-stream output.  Queued on the context's stream. */
 int glc_decode_range_device(glc_ctx *ctx, const glc_frames *in, uint64_t hop_begin,
                             uint64_t hop_end, float *d_out, uint64_t cap);
+
+/* The inverse transform alone: dequantisation (src/codec.rs:651-665) + MdctTables::imdct_block
+ * (:377-390) + window (:672-675) - or the raw-frame path (:626-644) - for every frame-channel of
+ * [frame_begin, frame_end) -> d_blocks[(frame-frame_begin)*channels + c][2048] f32, before any
+ * overlap-add.  Used for kernel-level timing and as the parity tap of the decode side (the
+ * counterpart of glc_mdct_forward_device).  Queued on the context's stream, not synchronised. */
+int glc_imdct_device(glc_ctx *ctx, const glc_frames *in, uint64_t frame_begin, uint64_t frame_end,
+                     float *d_blocks);
 
 /* Decoder::decode_streaming src/codec.rs:595-741: un-trimmed output delivered in chunks of at
  * least FRAMES_PER_CHUNK*1024*channels samples (AudioChunk, :81-85).  `begin` decodes on the

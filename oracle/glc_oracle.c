@@ -249,6 +249,8 @@ typedef struct enc_job {
   uint32_t ch;
   uint64_t f0, nf;
   float **padded;
+  uint64_t pad_base; /* padded[c][0] is element pad_base of the channel's padded array (0: whole array) */
+  uint64_t tap_f0;   /* taps row = (frame - tap_f0)*ch + c */
   const float *table, *window, *weights;
   const uint32_t *edges;
   uint32_t n_edges;
@@ -264,7 +266,7 @@ static void encode_one_frame(enc_job *J, uint64_t fi, float *block, float *coeff
                              float *scale_tmp, uint16_t *idx_all, int16_t *q_all) {
   const uint32_t ch = J->ch;
   for (uint32_t c = 0; c < ch; ++c) {
-    const float *slice = J->padded[c] + fi * N_HOP; /* :473-474 */
+    const float *slice = J->padded[c] + (fi * N_HOP - J->pad_base); /* :473-474 */
     for (uint32_t i = 0; i < N_FRAME; ++i) block[i] = slice[i] * J->window[i]; /* :476-481 */
     glo_mdct_block(J->table, J->norm, block, coeffs);                         /* :485 */
     float max_val = abs_max_floor(coeffs, 1e-10f);                            /* :488 */
@@ -279,7 +281,7 @@ static void encode_one_frame(enc_job *J, uint64_t fi, float *block, float *coeff
       raw_tmp[(size_t)c * N_FRAME + i] = sat_i16(s * 32767.0f);
     }
     if (J->taps) {
-      size_t m = (size_t)fi * ch + c;
+      size_t m = (size_t)(fi - J->tap_f0) * ch + c;
       if (J->taps->coeffs) memcpy(J->taps->coeffs + m * N_HOP, coeffs, sizeof(float) * N_HOP);
       if (J->taps->scales) J->taps->scales[m] = max_val;
       if (J->taps->nnz) J->taps->nnz[m] = n;
@@ -297,7 +299,7 @@ static void encode_one_frame(enc_job *J, uint64_t fi, float *block, float *coeff
   compressed += 64;
   size_t raw_size = (size_t)N_FRAME * ch * 2;
   int use_raw = (float)compressed >= ((float)raw_size * kCompressionThreshold);
-  if (J->taps && J->taps->is_raw) J->taps->is_raw[fi] = (uint8_t)use_raw;
+  if (J->taps && J->taps->is_raw) J->taps->is_raw[fi - J->tap_f0] = (uint8_t)use_raw;
 
   if (!J->frames) { /* timing mode: fold results so nothing is dead */
     unsigned long long acc = (unsigned long long)use_raw;
@@ -307,18 +309,22 @@ static void encode_one_frame(enc_job *J, uint64_t fi, float *block, float *coeff
   }
   enc_frame *F = &J->frames[fi - J->f0];
   F->is_raw = (uint8_t)use_raw;
+  /* scale / nnz are kept for raw frames too: the reference computes them before it decides
+   * (:488-493) and the device records carry them in every frame's header */
+  F->nnz = (uint32_t *)malloc(sizeof(uint32_t) * ch);
+  F->scale = (float *)malloc(sizeof(float) * ch);
+  for (uint32_t c = 0; c < ch; ++c) {
+    F->nnz[c] = nnz_tmp[c];
+    F->scale[c] = scale_tmp[c];
+  }
   if (use_raw) {
     F->raw = (int16_t *)malloc(sizeof(int16_t) * N_FRAME * ch);
     memcpy(F->raw, raw_tmp, sizeof(int16_t) * N_FRAME * ch);
   } else {
-    F->nnz = (uint32_t *)malloc(sizeof(uint32_t) * ch);
-    F->scale = (float *)malloc(sizeof(float) * ch);
     F->idx = (uint16_t **)malloc(sizeof(uint16_t *) * ch);
     F->q = (int16_t **)malloc(sizeof(int16_t *) * ch);
     for (uint32_t c = 0; c < ch; ++c) {
       uint32_t n = nnz_tmp[c];
-      F->nnz[c] = n;
-      F->scale[c] = scale_tmp[c];
       F->idx[c] = (uint16_t *)malloc(sizeof(uint16_t) * (n ? n : 1));
       F->q[c] = (int16_t *)malloc(sizeof(int16_t) * (n ? n : 1));
       memcpy(F->idx[c], idx_all + (size_t)c * N_HOP, n * sizeof(uint16_t));
@@ -443,7 +449,7 @@ int glo_encode(uint32_t sample_rate, const float *pcm, uint64_t n_samples, uint1
       wb_u8(&w, 1);
       wb_u64(&w, (uint64_t)N_FRAME * ch);
       wb_put(&w, F->raw, sizeof(int16_t) * N_FRAME * ch);
-      free(F->raw);
+      free(F->raw); free(F->nnz); free(F->scale);
     } else {
       wb_u64(&w, ch);
       for (uint32_t c = 0; c < ch; ++c) {
@@ -500,6 +506,79 @@ double glo_time_encode_frames(uint32_t sample_rate, const float *pcm, uint64_t n
   free(padded); free(table);
   if (atomic_load(&J.sink) == 0xFFFFFFFFFFFFFFFFull) return -2.0;
   return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+}
+
+/* Frames [f0, f1) of a stream of n_samples interleaved samples, computed from ONE SHARD of its
+ * PCM: `shard` holds per-channel samples [t0, t0 + t_count) (interleaved, shard[0] = sample t0 of
+ * channel 0).  Samples of the stream that lie outside the shard are poisoned with NaN, so a frame
+ * range whose halo is missing cannot silently agree with anything; samples outside the stream are
+ * the encoder's zero padding (src/codec.rs:433-447).  Output: the fixed-size frame records of the
+ * device path (include/glc.h glc_record_bytes): u32 is_raw | u32 0 | ch x {f32 scale, u32 nnz} |
+ * pad to 16 | i16 payload[ch][2048] (dense quantised row in [0, 1024) or the planar raw plane).
+ * Only the span of padded samples the range reads is materialised, so windows at the far end of
+ * hour-long streams cost nothing. */
+int glo_encode_range_records(uint32_t sample_rate, const float *shard, uint64_t t0, uint64_t t_count,
+                             uint64_t n_samples, uint16_t channels, uint64_t f0, uint64_t f1,
+                             int n_threads, uint8_t *records, const glo_taps *taps) {
+  uint64_t nf = glo_num_frames(n_samples, channels);
+  if (nf == 0 || f0 > f1 || f1 > nf) return -1;
+  if (f0 == f1) return 0;
+  const uint32_t ch = channels;
+  float *table = (float *)malloc(sizeof(float) * N_HOP * N_FRAME);
+  float window[N_FRAME], weights[N_HOP], norm;
+  uint32_t edges[GLO_MAX_BANDS];
+  glo_tables(table, window, &norm);
+  uint32_t n_edges = glo_perceptual(sample_rate, weights, edges);
+  const uint64_t base = f0 * N_HOP, span = (f1 - 1 - f0) * N_HOP + N_FRAME;
+  float **padded = (float **)malloc(sizeof(float *) * ch);
+  for (uint32_t c = 0; c < ch; ++c) {
+    uint64_t lc = n_samples > c ? (n_samples - c + ch - 1) / ch : 0; /* per_chan[c].len() */
+    padded[c] = (float *)calloc(span, sizeof(float));
+    for (uint64_t j = 0; j < span; ++j) {
+      uint64_t pi = base + j; /* index into padded[c]; real sample t = pi - 512 */
+      if (pi < 512) continue;
+      uint64_t t = pi - 512;
+      if (t >= lc) continue; /* trailing padding */
+      if (t < t0 || t - t0 >= t_count) padded[c][j] = NAN; /* inside the stream, outside the shard */
+      else padded[c][j] = shard[(t - t0) * ch + c];
+    }
+  }
+  enc_job J;
+  memset(&J, 0, sizeof J);
+  J.ch = ch; J.f0 = f0; J.nf = f1 - f0; J.padded = padded; J.pad_base = base; J.tap_f0 = f0;
+  J.table = table; J.window = window; J.weights = weights; J.edges = edges; J.n_edges = n_edges;
+  J.norm = norm; J.taps = taps;
+  J.frames = (enc_frame *)calloc(f1 - f0, sizeof(enc_frame));
+  atomic_init(&J.next, 0);
+  atomic_init(&J.sink, 0);
+  run_workers(encode_worker, &J, n_threads);
+  const uint64_t hdr = ((8ull + 8ull * ch) + 15ull) & ~15ull, rec = hdr + 2ull * N_FRAME * ch;
+  for (uint64_t k = 0; k < f1 - f0; ++k) {
+    enc_frame *F = &J.frames[k];
+    uint8_t *r = records + k * rec;
+    memset(r, 0, rec);
+    uint32_t is_raw = F->is_raw;
+    memcpy(r, &is_raw, 4);
+    int16_t *pay = (int16_t *)(r + hdr);
+    for (uint32_t c = 0; c < ch; ++c) {
+      memcpy(r + 8 + 8 * c, &F->scale[c], 4);
+      memcpy(r + 8 + 8 * c + 4, &F->nnz[c], 4);
+    }
+    if (F->is_raw) {
+      memcpy(pay, F->raw, sizeof(int16_t) * N_FRAME * ch);
+      free(F->raw); free(F->nnz); free(F->scale);
+    } else {
+      for (uint32_t c = 0; c < ch; ++c) {
+        for (uint32_t j = 0; j < F->nnz[c]; ++j) pay[(size_t)c * N_FRAME + F->idx[c][j]] = F->q[c][j];
+        free(F->idx[c]);
+        free(F->q[c]);
+      }
+      free(F->idx); free(F->q); free(F->nnz); free(F->scale);
+    }
+  }
+  for (uint32_t c = 0; c < ch; ++c) free(padded[c]);
+  free(padded); free(J.frames); free(table);
+  return 0;
 }
 
 /* ---------------------------------------------------------------- decode */

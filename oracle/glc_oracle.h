@@ -68,6 +68,15 @@ uint64_t glo_num_frames(uint64_t n_samples, uint16_t channels);
 int glo_encode(uint32_t sample_rate, const float *pcm, uint64_t n_samples, uint16_t channels,
                int n_threads, uint8_t **out_bytes, uint64_t *out_len, const glo_taps *taps);
 
+/* Frames [f0, f1) of a stream of n_samples interleaved samples computed from one shard of its PCM
+ * (per-channel samples [t0, t0+t_count), interleaved): the body of the rayon loop :462-541 per
+ * frame, written as the device path's fixed-size frame records (include/glc.h).  Stream samples
+ * outside the shard are poisoned with NaN (a missing halo cannot go unnoticed).  taps rows are
+ * relative to f0.  Returns 0, or -1 for a bad range / a stream the reference panics on. */
+int glo_encode_range_records(uint32_t sample_rate, const float *shard, uint64_t t0, uint64_t t_count,
+                             uint64_t n_samples, uint16_t channels, uint64_t f0, uint64_t f1,
+                             int n_threads, uint8_t *records, const glo_taps *taps);
+
 /* src/codec.rs:781-786 + :744-768 (+ decode_streaming :595-741): parse .glc bytes and decode.
  * Returns 0 and malloc'd interleaved f32 (glo_free), -1 on malformed input. */
 int glo_decode(const uint8_t *bytes, uint64_t len, int n_threads, float **out_pcm,

@@ -66,6 +66,10 @@ def lib():
         L.glo_time_encode_frames.argtypes = [C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint16,
                                              C.c_uint64, C.c_uint64, C.c_int]
         L.glo_time_encode_frames.restype = C.c_double
+        L.glo_encode_range_records.argtypes = [C.c_uint32, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
+                                               C.c_uint16, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p,
+                                               C.POINTER(_Taps)]
+        L.glo_encode_range_records.restype = C.c_int
         L.glo_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
@@ -170,6 +174,39 @@ def encode(pcm: np.ndarray, sample_rate: int, channels: int, taps: bool = False,
     res.glc = C.string_at(out, n.value)
     lib().glo_free(out)
     return res
+
+
+def record_bytes(channels: int) -> int:
+    return ((8 + 8 * channels) + 15) // 16 * 16 + 2 * FRAME * channels
+
+
+def encode_range_records(shard: np.ndarray, t0: int, t_count: int, n_samples: int, sample_rate: int,
+                         channels: int, f0: int, f1: int, taps: bool = False, n_threads: int = 0):
+    """Frames [f0, f1) of a stream from ONE shard of its PCM (per-channel samples [t0, t0+t_count)),
+    as the device path's fixed-size records; stream samples outside the shard are NaN-poisoned.
+    -> (records uint8, OracleEncode taps with rows relative to f0, or None)."""
+    shard = np.ascontiguousarray(shard, np.float32).reshape(-1)
+    assert shard.size >= min(t_count * channels, max(0, n_samples - t0 * channels)), "shard shorter than it claims"
+    nf = f1 - f0
+    rec = np.zeros(nf * record_bytes(channels), np.uint8)
+    t = _Taps()
+    res = None
+    if taps:
+        M = nf * channels
+        res = OracleEncode(b"", nf, np.empty((M, HOP), np.float32), np.empty(M, np.float32),
+                           np.empty(M, np.uint32), np.empty(nf, np.uint8), np.empty((M, HOP), np.int16))
+        t.coeffs, t.scales, t.nnz = _p(res.coeffs), _p(res.scales), _p(res.nnz)
+        t.is_raw, t.dense_q = _p(res.is_raw), _p(res.dense_q)
+    # the C side reads shard[(t - t0)*ch + c] only for samples inside the stream
+    need = max(0, min(t_count * channels, n_samples - t0 * channels))
+    buf = shard if shard.size >= t_count * channels else np.concatenate(
+        [shard, np.zeros(t_count * channels - shard.size, np.float32)])
+    del need
+    rc = lib().glo_encode_range_records(sample_rate, _p(buf), t0, t_count, n_samples, channels, f0, f1,
+                                        n_threads, _p(rec), C.byref(t) if taps else None)
+    if rc != 0:
+        raise ValueError("oracle range encode failed (bad range or a stream the reference panics on)")
+    return rec, res
 
 
 def decode(glc: bytes, n_threads: int = 0):

@@ -631,3 +631,212 @@ def test_long_ragged_streams_and_shards(torch_cuda, ch):
     e.encode_range_device(d.data_ptr() + 4, 0, plan.per_channel, x.size, ch, 0, plan.n_frames, d_rec.data_ptr(), 0)
     e.synchronize()
     assert np.array_equal(d_rec.cpu().numpy(), whole)
+
+
+# ---------------------------------------------------------------------------------------
+# Direct coefficient-bit parity of the two hand-scheduled transforms: the
+# launches the benchmark and long streams actually take - k_mdct_fwd_sched (513..4095 rows) and
+# the five k_mdct_fwd_dma instantiations (>= 4096 rows; ch 1 / 2 / 4 / 8 = dwordx4 segment loader,
+# 3 = per-row loader) - compared f32 bit for f32 bit with the oracle's mdct_block on windows of
+# frames: the stream start (leading zero padding), a noise burst, the ragged end (partially
+# out-of-range loads), and the same through a shard whose device buffer starts mid-stream.
+# Reference: src/codec.rs:476-485, :359-374.
+# ---------------------------------------------------------------------------------------
+
+def _k1_stream(ch, frames, seed):
+    sr = 48000
+    rng = np.random.default_rng(seed)
+    t = np.arange(frames * 1024, dtype=np.float64)[:, None]
+    x = (np.sin(2 * np.pi * rng.uniform(60, 9000, (1, ch)) * t / sr) * 0.4).astype(np.float32)
+    mid = (frames // 2) * 1024
+    x[mid:mid + 6000] = rng.standard_normal((6000, ch)).astype(np.float32) * 0.3   # noise burst
+    x[-3000:] += rng.standard_normal((3000, ch)).astype(np.float32) * 0.2          # activity in the last frames
+    n = frames * 1024 * ch - 300 * ch - (ch - 1)                                    # ragged: not a whole sample frame
+    return x.reshape(-1)[:n], sr
+
+
+@pytest.mark.parametrize("ch", [1, 2, 4, 8, 3])
+@pytest.mark.parametrize("kernel", ["sched", "dma"])
+def test_k1_large_launch_coefficient_bits(torch_cuda, ch, kernel):
+    rows_wanted = 2300 if kernel == "sched" else 4096 + 333
+    frames = -(-rows_wanted // ch) + 3
+    x, sr = _k1_stream(ch, frames, 100 + ch)
+    plan = glc_amd.plan_encode(x.size, ch)
+    nf, L = plan.n_frames, plan.per_channel
+    enc = glc_amd.Encoder(sr)
+    W = 5  # frames per oracle window
+
+    def launch_and_check(f0, t0, t_count, windows):
+        rows = (nf - f0) * ch
+        assert (513 <= rows <= 4095) if kernel == "sched" else rows >= 4096
+        lo, hi = t0 * ch, min((t0 + t_count) * ch, x.size)
+        d_pcm = torch_cuda.from_numpy(x[lo:hi].copy()).cuda()
+        d_coef = torch_cuda.full((rows, 1024), float("nan"), dtype=torch_cuda.float32, device="cuda")
+        torch_cuda.cuda.synchronize()
+        enc.mdct_forward_device(d_pcm.data_ptr(), t0, t_count, x.size, ch, f0, nf, d_coef.data_ptr())
+        enc.synchronize()
+        coef = d_coef.cpu().numpy()
+        assert not np.isnan(coef).any()
+        for a in windows:
+            b = min(a + W, nf)
+            _, ref = O.encode_range_records(x[lo:hi], t0, t_count, x.size, sr, ch, a, b, taps=True)
+            got = coef[(a - f0) * ch:(b - f0) * ch]
+            assert np.array_equal(bits(got), bits(ref.coeffs)), \
+                f"{kernel} ch={ch}: {(bits(got) != bits(ref.coeffs)).sum()} coefficient words differ in frames [{a},{b})"
+
+    # whole stream on the device: start, noise burst, a tile boundary (row 128k), ragged end
+    launch_and_check(0, 0, L, [0, nf // 2 - 2, (128 * 3) // ch, nf - W])
+    # a shard: frames [f0, nf) from a buffer that holds only [1024 f0 - 512, L)
+    f0 = 2 if kernel == "sched" else 3
+    if (nf - f0) * ch >= (513 if kernel == "sched" else 4096):
+        launch_and_check(f0, f0 * 1024 - 512, L - (f0 * 1024 - 512), [f0, nf // 2 - 1, nf - W])
+
+
+def test_k1_small_launch_tile_edges(torch_cuda):
+    """The <= 512-row kernel across its 32-row tile edges and with a partial last tile."""
+    for ch, frames in ((1, 70), (2, 255), (3, 170), (8, 64)):
+        x, sr = _k1_stream(ch, frames, 7 * ch)
+        plan = glc_amd.plan_encode(x.size, ch)
+        nf = plan.n_frames
+        assert nf * ch <= 512
+        d_pcm = torch_cuda.from_numpy(x).cuda()
+        d_coef = torch_cuda.zeros((nf * ch, 1024), dtype=torch_cuda.float32, device="cuda")
+        enc = glc_amd.Encoder(sr)
+        torch_cuda.cuda.synchronize()
+        enc.mdct_forward_device(d_pcm.data_ptr(), 0, plan.per_channel, x.size, ch, 0, nf, d_coef.data_ptr())
+        enc.synchronize()
+        coef = d_coef.cpu().numpy()
+        for a in (0, nf // 2, nf - 4):
+            _, ref = O.encode_range_records(x, 0, plan.per_channel, x.size, sr, ch, a, a + 4, taps=True)
+            assert np.array_equal(bits(coef[a * ch:(a + 4) * ch]), bits(ref.coeffs))
+
+
+# ---------------------------------------------------------------------------------------
+# Decode-side tap: glc_imdct_device (dequant + imdct_block + window, raw frames) against the oracle's
+# imdct_block, f32 bit equality, before any overlap-add.  Reference: src/codec.rs:626-675, :377-390.
+# ---------------------------------------------------------------------------------------
+
+def _ref_blocks(glc_bytes, frames):
+    g = parse_glc(glc_bytes)
+    ch = g["channels"]
+    _, w, _ = O.tables()
+    out = np.zeros((len(frames) * ch, 2048), np.float32)
+    for j, f in enumerate(frames):
+        fr = g["frames"][f]
+        for c in range(ch):
+            if fr["raw"] is not None:
+                raw = fr["raw"]
+                idx = np.arange(2048) * ch + c
+                ok = idx < raw.size
+                v = np.zeros(2048, np.float32)
+                v[ok] = raw[idx[ok]].astype(np.float32) / np.float32(32767.0)      # :638
+                out[j * ch + c] = v
+                continue
+            k, q = fr["lists"][c]
+            coeffs = np.zeros(1024, np.float32)
+            scale = np.maximum(fr["scales"][c], np.float32(1e-12))                 # :653
+            for kk, qq in zip(k.tolist(), q.tolist()):
+                if kk < 1024:
+                    coeffs[kk] = (np.float32(qq) / np.float32(32768.0)) * scale    # :663
+            out[j * ch + c] = O.imdct_block(coeffs) * w                            # :669, :674
+    return out
+
+
+@pytest.mark.parametrize("ch,n_per", [(1, 40000), (2, 30000), (3, 9000), (6, 8000)])
+def test_imdct_tap_bit_exact(torch_cuda, ch, n_per):
+    sr = 48000
+    x = np.concatenate([gen_chord(sr, ch, n_per, n_tones=9), gen_noise(sr, ch, 0.08, 5), gen_chord(sr, ch, 5000, seed=3)])
+    ref = O.encode(x, sr, ch)
+    ea = glc_amd.EncodedAudio.from_bytes(ref.glc)
+    nf = ea.info().n_frames
+    assert 0 < ea.info().n_raw_frames < nf
+    dec = glc_amd.Decoder(ch, sr)
+    for f0, f1 in ((0, nf), (3, nf - 2), (5, 6)):
+        d_blk = torch_cuda.full(((f1 - f0) * ch, 2048), float("nan"), dtype=torch_cuda.float32, device="cuda")
+        torch_cuda.cuda.synchronize()
+        dec.imdct_device(ea, f0, f1, d_blk.data_ptr())
+        dec.synchronize()
+        got = d_blk.cpu().numpy()
+        frames = sorted(set([f0, f0 + 1, (f0 + f1) // 2, f1 - 1] + list(range(f0, min(f1, f0 + 12)))))
+        frames = [f for f in frames if f0 <= f < f1]
+        want = _ref_blocks(ref.glc, frames)
+        for j, f in enumerate(frames):
+            a = got[(f - f0) * ch:(f - f0 + 1) * ch]
+            assert np.array_equal(bits(a), bits(want[j * ch:(j + 1) * ch])), (ch, f0, f1, f)
+
+
+def test_decode_reuses_resident_rows(torch_cuda):
+    """A context keeps the sparse rows of the last stream it decoded on the device: decoding the same
+    EncodedAudio again (any entry point) uploads nothing and gives the same bits; another stream in
+    between replaces them."""
+    sr, ch = 44100, 2
+    xa = gen_chord(sr, ch, 30000, n_tones=6)
+    xb = np.concatenate([gen_chord(sr, ch, 12000, seed=5), gen_noise(sr, ch, 0.1, 8)])
+    ea, eb = glc_amd.Encoder(sr).encode(xa, ch), glc_amd.Encoder(sr).encode(xb, ch)
+    ra, rb = O.decode(ea.to_bytes())[0], O.decode(eb.to_bytes())[0]
+    dec = glc_amd.Decoder(ch, sr)
+    for _ in range(2):
+        assert np.array_equal(bits(dec.decode(ea)), bits(ra))
+        assert np.array_equal(bits(dec.decode(ea)), bits(ra))
+        chunks = np.concatenate([c.samples for c in dec.decode_streaming(ea)])
+        assert np.array_equal(bits(chunks[512:512 + ra.size]), bits(ra))
+        assert np.array_equal(bits(dec.decode(eb)), bits(rb))
+    # a stream reloaded from bytes is a different object with the same content
+    ea2 = glc_amd.EncodedAudio.from_bytes(ea.to_bytes())
+    assert np.array_equal(bits(dec.decode(ea2)), bits(ra))
+    del ea2
+    assert np.array_equal(bits(dec.decode(ea)), bits(ra))
+
+
+def test_infinite_scale_with_stored_zero(torch_cuda):
+    """A stored q == 0 under an infinite scale dequantises to NaN (0 * inf, src/codec.rs:663) and
+    poisons the frame - whatever order the list is in (canonical lists go to the device as stored,
+    others through the host canonicalisation)."""
+    import struct
+    sr, ch = 44100, 1
+    inf = float("inf")
+    for lists, scales in [([[(3, 0), (9, 100)], [(4, 7)]], [inf, 0.25]),        # ascending: canonical path
+                          ([[(9, 100), (3, 0)], [(4, 7)]], [inf, 0.25]),        # descending: host canonicalisation
+                          ([[(3, 0), (3, 0), (1, 5)], [(4, 7)]], [inf, inf]),   # duplicate + infinite everywhere
+                          ([[(3, 0)], [(2000, 0), (5, 0)]], [0.5, inf])]:       # finite scale: zero stays harmless
+        body = b""
+        for l, sc in zip(lists, scales):
+            body += struct.pack("<Q", 1) + struct.pack("<Q", len(l)) + b"".join(struct.pack("<Hh", i, q) for i, q in l)
+            body += struct.pack("<Qf", 1, sc) + b"\x00"
+        data = struct.pack("<IHQQ", sr, ch, 3000, len(lists)) + body + struct.pack("<IIQ", 512, 0, 3000)
+        ref, _, _ = O.decode(data)
+        dec = glc_amd.Decoder(ch, sr).decode(glc_amd.EncodedAudio.from_bytes(data))
+        assert np.array_equal(bits(dec), bits(ref)), (lists, scales)
+
+
+def test_device_compaction_blob_equals_host_twin(torch_cuda):
+    """glc_compact_device_records == glc_compact_records byte for byte (deterministic padding), on
+    compressed + raw frames, for several channel counts, an empty range and a too-small buffer."""
+    for sr, ch in ((44100, 1), (48000, 2), (44100, 3), (96000, 8)):
+        x = np.concatenate([gen_chord(sr, ch, 9000), gen_noise(sr, ch, 0.15, 5), gen_chord(sr, ch, 3000, seed=2)])
+        plan = glc_amd.plan_encode(x.size, ch)
+        recs, _ = device_encode(torch_cuda, x, sr, ch, want_coeffs=False)
+        d_rec = torch_cuda.from_numpy(recs).cuda()
+        cap = glc_amd.compact_bound(ch, plan.n_frames)
+        d_blob = torch_cuda.full((cap,), 0xAB, dtype=torch_cuda.uint8, device="cuda")
+        enc = glc_amd.Encoder(sr)
+        torch_cuda.cuda.synchronize()
+        info = enc.compact_device_records(d_rec.data_ptr(), plan.n_frames, ch, d_blob.data_ptr(), cap)
+        host = glc_amd.compact_records(recs, ch)
+        assert info.bytes == host.size and info.n_frames == plan.n_frames and info.n_raw_rows > 0
+        assert np.array_equal(d_blob.cpu().numpy()[:info.bytes], host)
+        out = glc_amd.EncodedAudio.from_compact(sr, x.size, ch, [d_blob.cpu().numpy()[:info.bytes]])
+        assert out.to_bytes() == O.encode(x, sr, ch).glc
+        # two shards compacted separately assemble to the same stream
+        cut = plan.n_frames // 2 + 1
+        rb = glc_amd.lib.glc_record_bytes(ch)
+        blobs = []
+        for a, b in ((0, cut), (cut, plan.n_frames)):
+            i2 = enc.compact_device_records(d_rec.data_ptr() + a * rb, b - a, ch, d_blob.data_ptr(), cap)
+            blobs.append(d_blob.cpu().numpy()[:i2.bytes].copy())
+        assert glc_amd.EncodedAudio.from_compact(sr, x.size, ch, blobs).to_bytes() == out.to_bytes()
+        # empty range; undersized buffer
+        i0 = enc.compact_device_records(0, 0, ch, d_blob.data_ptr(), cap)
+        assert (i0.n_frames, i0.n_pairs, i0.n_raw_rows) == (0, 0, 0) and i0.bytes == glc_amd.compact_records(recs[:0], ch).size
+        with pytest.raises(glc_amd.GlcError):
+            enc.compact_device_records(d_rec.data_ptr(), plan.n_frames, ch, d_blob.data_ptr(), cap - 1)
