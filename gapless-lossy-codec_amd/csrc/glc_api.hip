@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include "../../include/glc_debug.h"
 #include "glc_common.h"
 #include "glc_kernels.h"
 
@@ -94,6 +95,7 @@ struct glc_ctx {
   // decode session (decode_prepare / round_launch): device-resident sparse rows + position
   glc::DecodeRows dec_rows{};
   uint64_t dec_uid = 0;  // glc_frames::uid whose rows dec_meta holds (0: none)
+  int d1_variant = 0;    // include/glc_debug.h: which inverse-transform kernel / path to launch
   uint32_t dec_ch = 0;
   uint64_t dec_frames = 0, dec_next = 0;
   bool stream_open = false;  // glc_decode_stream_begin called, last chunk not yet delivered
@@ -357,8 +359,9 @@ int glc_encode_range_device(glc_ctx *ctx, const float *d_pcm, uint64_t t0, uint6
     float *coef = d_coeffs ? d_coeffs + (f - frame_begin) * ch * glc::kHop : static_cast<float *>(ctx->coef.p);
     uint8_t *r = recs + (f - frame_begin) * rec;
     GLC_HIP(ctx, glc::launch_mdct_forward(ctx->dev, view, f, M, coef, ctx->stream));
-    GLC_HIP(ctx, glc::launch_quantize(ctx->dev, coef, M, ch, r, ctx->stream));
-    GLC_HIP(ctx, glc::launch_decide_raw(ctx->dev, view, f, static_cast<uint32_t>(nf), r, ctx->stream));
+    bool decided = false;
+    GLC_HIP(ctx, glc::launch_quantize(ctx->dev, coef, M, ch, view, f, r, ctx->stream, &decided));
+    if (!decided) GLC_HIP(ctx, glc::launch_decide_raw(ctx->dev, view, f, static_cast<uint32_t>(nf), r, ctx->stream));
   }
   return GLC_OK;
 }
@@ -440,14 +443,55 @@ int glc_frames_from_device_records(glc_ctx *ctx, const void *d_records, uint64_t
   glc_compact_info info;
   int rc = glc_compact_device_records(ctx, d_records, n_frames, channels, ctx->pack_blob.p, ctx->pack_blob.cap, &info);
   if (rc != GLC_OK) return rc;
-  // only the bitstream's payload crosses PCIe, through pinned memory
-  GLC_HIP(ctx, ctx->host_stage.reserve(info.bytes));
-  GLC_HIP(ctx, hipMemcpyAsync(ctx->host_stage.p, ctx->pack_blob.p, info.bytes, hipMemcpyDeviceToHost, ctx->stream));
+  // Only the bitstream's payload crosses PCIe, and it lands where it stays: the (u16, i16) pairs
+  // and the raw planes are copied straight into the EncodedAudio's own pools, the small per-frame /
+  // per-row metadata through pinned staging.
+  const uint32_t ch = channels;
+  const uint64_t raw_off = glc::compact_raw_offset(l, info.n_pairs);
+  std::unique_ptr<glc_frames> F(new (std::nothrow) glc_frames);
+  if (!F) return fail(ctx, GLC_ENOMEM, "glc_frames_from_device_records: host allocation failed");
+  try {
+    F->sample_rate = ctx->sample_rate;
+    F->channels = channels;
+    F->total_samples = n_samples;           // src/codec.rs:423,555
+    F->encoder_delay = plan.encoder_delay;  // :547
+    F->padding = plan.padding;              // :546
+    F->original_length = n_samples;         // :562
+    F->n_frames = n_frames;
+    F->list_begin.assign(n_frames + 1, 0);
+    F->scale_begin.assign(n_frames + 1, 0);
+    F->raw_begin.assign(n_frames + 1, 0);
+    F->raw_tag.resize(n_frames);
+    F->pairs.resize(info.n_pairs);
+    F->raw.resize(info.n_raw_rows * glc::kFrame);
+    const uint64_t n_comp_rows = n_frames * ch - info.n_raw_rows;
+    F->list_off.reserve(n_comp_rows + 1);
+    F->scales.reserve(n_comp_rows);
+  } catch (const std::bad_alloc &) {
+    return fail(ctx, GLC_ENOMEM, "glc_frames_from_device_records: host allocation failed");
+  }
+  GLC_HIP(ctx, ctx->host_stage.reserve(l.o_pairs));
+  const uint8_t *blob = static_cast<const uint8_t *>(ctx->pack_blob.p);
+  GLC_HIP(ctx, hipMemcpyAsync(ctx->host_stage.p, blob, l.o_pairs, hipMemcpyDeviceToHost, ctx->stream));
+  if (info.n_pairs)
+    GLC_HIP(ctx, hipMemcpyAsync(F->pairs.data(), blob + l.o_pairs, info.n_pairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (info.n_raw_rows)
+    GLC_HIP(ctx, hipMemcpyAsync(F->raw.data(), blob + raw_off, info.n_raw_rows * glc::kFrame * 2, hipMemcpyDeviceToHost,
+                                ctx->stream));
   GLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  const void *blobs[1] = {ctx->host_stage.p};
-  const uint64_t sizes[1] = {info.bytes};
-  rc = glc::frames_from_compact(ctx->sample_rate, n_samples, channels, blobs, sizes, 1, /*trusted=*/true, out);
+  glc::CompactHeader h;
+  std::memcpy(&h, ctx->host_stage.p, sizeof h);
+  bool canonical = true;
+  try {
+    rc = glc::index_compact_meta(F.get(), ch, h, static_cast<const uint8_t *>(ctx->host_stage.p), 0, 0, 0, /*trusted=*/true,
+                                 &canonical);
+    F->list_off.push_back(info.n_pairs);
+  } catch (const std::bad_alloc &) {
+    return fail(ctx, GLC_ENOMEM, "glc_frames_from_device_records: host allocation failed");
+  }
   if (rc != GLC_OK) return fail(ctx, rc, std::string("glc_frames_from_device_records: ") + glc_last_error(nullptr));
+  F->lists_canonical = true;  // ballot-packed in ascending k
+  *out = F.release();
   return GLC_OK;
 }
 
@@ -653,7 +697,8 @@ int round_launch(glc_ctx *ctx, uint64_t round_frames, bool flush_at_full, float 
   if (f0 == 0) GLC_HIP(ctx, hipMemsetAsync(blocks, 0, slot * sizeof(float), ctx->stream));  // overlap = 0.0, :601
   if (n)
     GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, static_cast<uint32_t>(f0 * ch),
-                                        static_cast<uint32_t>(n * ch), ch, blocks + slot, ctx->stream));
+                                        static_cast<uint32_t>(n * ch), ch, blocks + slot, ctx->stream,
+                                        ctx->d1_variant));
   GLC_HIP(ctx, glc::launch_overlap_add(blocks, static_cast<int64_t>(f0) - 1, nf, ch, f0, f0 + n + (last ? 1 : 0), dout,
                                        ctx->stream));
   if (!last)
@@ -693,14 +738,15 @@ int decode_hops_prepared(glc_ctx *ctx, uint64_t hop_begin, uint64_t hop_end, flo
     GLC_HIP(ctx, hipMemsetAsync(blocks, 0, slot * sizeof(float), ctx->stream));  // overlap = 0.0, :601
   else
     GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, static_cast<uint32_t>((hop_begin - 1) * ch), ch, ch,
-                                        blocks, ctx->stream));
+                                        blocks, ctx->stream, ctx->d1_variant));
   uint64_t f0 = hop_begin;
   do {
     const uint64_t nchunk = f0 < f_end ? std::min(chunk, f_end - f0) : 0;
     const bool tail = f0 + nchunk == nf && hop_end == nf + 1;  // this round also emits the bare overlap tail
     if (nchunk)
       GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, static_cast<uint32_t>(f0 * ch),
-                                          static_cast<uint32_t>(nchunk * ch), ch, blocks + slot, ctx->stream));
+                                          static_cast<uint32_t>(nchunk * ch), ch, blocks + slot, ctx->stream,
+                                          ctx->d1_variant));
     GLC_HIP(ctx, glc::launch_overlap_add(blocks, static_cast<int64_t>(f0) - 1, nf, ch, f0, f0 + nchunk + (tail ? 1 : 0),
                                          d_out + (f0 - hop_begin) * glc::kHop * ch, ctx->stream));
     f0 += nchunk + (tail ? 1 : 0);
@@ -815,7 +861,14 @@ int glc_imdct_device(glc_ctx *ctx, const glc_frames *in, uint64_t frame_begin, u
   DeviceGuard guard(ctx->device);
   const uint32_t ch = ctx->dec_ch;
   GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, static_cast<uint32_t>(frame_begin * ch),
-                                      static_cast<uint32_t>((frame_end - frame_begin) * ch), ch, d_blocks, ctx->stream));
+                                      static_cast<uint32_t>((frame_end - frame_begin) * ch), ch, d_blocks, ctx->stream,
+                                      ctx->d1_variant));
+  return GLC_OK;
+}
+
+int glc_debug_set_imdct_variant(glc_ctx *ctx, int variant) {
+  if (!ctx || variant < 0 || variant > 3) return fail(ctx, GLC_EINVAL, "glc_debug_set_imdct_variant: variant must be 0..3");
+  ctx->d1_variant = variant;
   return GLC_OK;
 }
 

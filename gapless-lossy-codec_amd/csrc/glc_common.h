@@ -88,6 +88,8 @@ void set_global_error(const std::string &msg);
 
 // Host assembly of EncodedAudio from compact blobs in frame order (glc_frames_from_compact).
 // `trusted`: the blobs were produced by this process's own pack kernels (lists known canonical).
+int index_compact_meta(glc_frames *F, uint32_t ch, const CompactHeader &h, const uint8_t *meta, uint64_t f_at,
+                       uint64_t p_at, uint64_t r_at, bool trusted, bool *canonical);
 int frames_from_compact(uint32_t sample_rate, uint64_t n_samples, uint16_t channels, const void *const *blobs,
                         const uint64_t *blob_bytes, uint32_t n_blobs, bool trusted, glc_frames **out);
 

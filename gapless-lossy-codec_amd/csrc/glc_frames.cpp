@@ -65,6 +65,62 @@ uint64_t next_frames_uid() {
   return counter.fetch_add(1, std::memory_order_relaxed) + 1;
 }
 
+// Index vectors of EncodedAudio for the frames of ONE compact blob whose payload (pairs, raw planes)
+// already sits in F->pairs / F->raw at p_at / r_at: per-frame raw tags, list offsets, scales.  `meta`
+// points at the blob's first o_pairs bytes (header + raw flags + scales + counts).  Untrusted blobs
+// are checked for canonical (strictly ascending, < 1024) lists on the way.
+int index_compact_meta(glc_frames *F, uint32_t ch, const CompactHeader &h, const uint8_t *meta, uint64_t f_at,
+                       uint64_t p_at, uint64_t r_at, bool trusted, bool *canonical) {
+  const CompactLayout l = compact_layout(ch, h.n_frames);
+  const uint8_t *israw = meta + l.o_israw;
+  const float *scale = reinterpret_cast<const float *>(meta + l.o_scale);
+  const uint32_t *cnt = reinterpret_cast<const uint32_t *>(meta + l.o_cnt);
+  const uint32_t *pairs = F->pairs.data() + p_at;
+  uint64_t p_in = 0, raw_rows_in = 0;
+  for (uint64_t f = 0; f < h.n_frames; ++f) {
+    const uint64_t fo = f_at + f;
+    F->raw_tag[fo] = israw[f] ? 1 : 0;
+    if (israw[f]) {
+      raw_rows_in += ch;
+      for (uint32_t c = 0; c < ch; ++c)
+        if (cnt[f * ch + c] != 0) {
+          set_global_error("glc_frames_from_compact: raw frame with a sparse list");
+          return GLC_EFORMAT;
+        }
+    } else {
+      for (uint32_t c = 0; c < ch; ++c) {
+        const uint32_t n = cnt[f * ch + c];
+        if (n > kHop || p_in + n > h.n_pairs) {
+          set_global_error("glc_frames_from_compact: corrupt blob (row counts exceed the pair pool)");
+          return GLC_EFORMAT;
+        }
+        if (!trusted && *canonical) {
+          int32_t last = -1;
+          for (uint32_t j = 0; j < n; ++j) {
+            const int32_t k = static_cast<int32_t>(pairs[p_in + j] & 0xFFFFu);
+            if (k <= last || k >= static_cast<int32_t>(kHop)) {
+              *canonical = false;
+              break;
+            }
+            last = k;
+          }
+        }
+        F->list_off.push_back(p_at + p_in);
+        F->scales.push_back(scale[f * ch + c]);
+        p_in += n;
+      }
+    }
+    F->list_begin[fo + 1] = F->list_off.size();
+    F->scale_begin[fo + 1] = F->scales.size();
+    F->raw_begin[fo + 1] = r_at + raw_rows_in * kFrame;
+  }
+  if (p_in != h.n_pairs || raw_rows_in != h.n_raw_rows) {
+    set_global_error("glc_frames_from_compact: corrupt blob (section totals disagree with the header)");
+    return GLC_EFORMAT;
+  }
+  return GLC_OK;
+}
+
 int frames_from_compact(uint32_t sample_rate, uint64_t n_samples, uint16_t channels, const void *const *blobs,
                         const uint64_t *blob_bytes, uint32_t n_blobs, bool trusted, glc_frames **out) {
   if (!out || (n_blobs && (!blobs || !blob_bytes))) return GLC_EINVAL;
@@ -135,55 +191,12 @@ int frames_from_compact(uint32_t sample_rate, uint64_t n_samples, uint16_t chann
       const CompactHeader &h = hdrs[b];
       const CompactLayout l = compact_layout(ch, h.n_frames);
       const uint8_t *base = static_cast<const uint8_t *>(blobs[b]);
-      const uint8_t *israw = base + l.o_israw;
-      const float *scale = reinterpret_cast<const float *>(base + l.o_scale);
-      const uint32_t *cnt = reinterpret_cast<const uint32_t *>(base + l.o_cnt);
       const uint32_t *pairs = reinterpret_cast<const uint32_t *>(base + l.o_pairs);
       const int16_t *raw = reinterpret_cast<const int16_t *>(base + compact_raw_offset(l, h.n_pairs));
       if (h.n_pairs) std::memcpy(F->pairs.data() + p_at, pairs, h.n_pairs * 4);
       if (h.n_raw_rows) std::memcpy(F->raw.data() + r_at, raw, h.n_raw_rows * kFrame * 2);
-      uint64_t p_in = 0, raw_rows_in = 0;
-      for (uint64_t f = 0; f < h.n_frames; ++f) {
-        const uint64_t fo = f_at + f;
-        F->raw_tag[fo] = israw[f] ? 1 : 0;
-        if (israw[f]) {
-          raw_rows_in += ch;
-          for (uint32_t c = 0; c < ch; ++c)
-            if (cnt[f * ch + c] != 0) {
-              set_global_error("glc_frames_from_compact: raw frame with a sparse list");
-              return GLC_EFORMAT;
-            }
-        } else {
-          for (uint32_t c = 0; c < ch; ++c) {
-            const uint32_t n = cnt[f * ch + c];
-            if (n > kHop || p_in + n > h.n_pairs) {
-              set_global_error("glc_frames_from_compact: corrupt blob (row counts exceed the pair pool)");
-              return GLC_EFORMAT;
-            }
-            if (!trusted && canonical) {
-              int32_t last = -1;
-              for (uint32_t j = 0; j < n; ++j) {
-                const int32_t k = static_cast<int32_t>(pairs[p_in + j] & 0xFFFFu);
-                if (k <= last || k >= static_cast<int32_t>(kHop)) {
-                  canonical = false;
-                  break;
-                }
-                last = k;
-              }
-            }
-            F->list_off.push_back(p_at + p_in);
-            F->scales.push_back(scale[f * ch + c]);
-            p_in += n;
-          }
-        }
-        F->list_begin[fo + 1] = F->list_off.size();
-        F->scale_begin[fo + 1] = F->scales.size();
-        F->raw_begin[fo + 1] = r_at + raw_rows_in * kFrame;
-      }
-      if (p_in != h.n_pairs || raw_rows_in != h.n_raw_rows) {
-        set_global_error("glc_frames_from_compact: corrupt blob (section totals disagree with the header)");
-        return GLC_EFORMAT;
-      }
+      const int rc = index_compact_meta(F.get(), ch, h, base, f_at, p_at, r_at, trusted, &canonical);
+      if (rc != GLC_OK) return rc;
       f_at += h.n_frames;
       p_at += h.n_pairs;
       r_at += h.n_raw_rows * kFrame;

@@ -32,10 +32,12 @@ struct PcmView {
 // K1: windowed forward MDCT of rows [0, M) (row = (frame - frame_begin)*ch + c) -> coef[M][1024].
 hipError_t launch_mdct_forward(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin,
                                uint32_t M, float *coef, hipStream_t s);
-// K2: scale, masking thresholds, quantiser -> record header {scale,nnz} + dense i16 row.
-hipError_t launch_quantize(const DeviceTables &t, const float *coef, uint32_t M, uint32_t ch,
-                           uint8_t *records, hipStream_t s);
-// K3: per-frame raw-vs-compressed decision and raw fallback plane.
+// K2: scale, masking thresholds, quantiser -> record header {scale,nnz} + dense i16 row.  For 1 / 2 /
+// 4 channels the kernel also takes the raw-vs-compressed decision and writes the raw plane of raw
+// frames (*decided = true: do not launch K3); `pcm` / `frame_begin` are what that needs.
+hipError_t launch_quantize(const DeviceTables &t, const float *coef, uint32_t M, uint32_t ch, const PcmView &pcm,
+                           uint64_t frame_begin, uint8_t *records, hipStream_t s, bool *decided);
+// K3: per-frame raw-vs-compressed decision and raw fallback plane (channel counts K2 does not decide).
 hipError_t launch_decide_raw(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin,
                              uint32_t n_frames, uint8_t *records, hipStream_t s);
 
@@ -61,8 +63,10 @@ struct DecodeRows {
   const uint64_t *row_raw_len;
   const int16_t *raw_pool;
 };
+// variant: 0 = shipped (k_imdct_chan<8>, path chosen per group); 1 = one row per workgroup (the
+// cross-check kernel); 2 / 3 = k_imdct_chan<8> forced onto its sparse / dense path.
 hipError_t launch_imdct_rows(const DeviceTables &t, const DecodeRows &rows, uint32_t row_begin,
-                             uint32_t M, uint32_t ch, float *blocks, hipStream_t s);
+                             uint32_t M, uint32_t ch, float *blocks, hipStream_t s, int variant = 0);
 // D2: overlap-add + interleave of hops [hop_begin, hop_end) into out (hop h = second half of
 // frame h-1 + first half of frame h; hop n_frames is the bare overlap tail).  `blocks` holds
 // frames blk_frame0, blk_frame0+1, ... (blk_frame0 may be -1: a zero "frame before the first").

@@ -13,8 +13,6 @@
 //   K3 k_decide_raw    :496-502 (raw plane) + :505-540 (size estimate, decision)
 //   D1 k_imdct_rows    :626-644 (raw frames), :651-665 (dequant), :377-390 (imdct), :672-675
 //   D2 k_overlap_add   :688-705 (overlap-add + interleave), :722-729 (tail)
-#include <cstdlib>
-
 #include "glc_kernels.h"
 #include "glc_mdct_fwd.hpp"
 
@@ -51,18 +49,24 @@ __device__ __forceinline__ short sat_i16(float x) {
 // K1 (forward MDCT) lives in glc_mdct_fwd.hpp.
 
 // ------------------------------------------------------------------------------------------
-// K2: scale, masking thresholds, quantiser.  A wavefront owns 4 consecutive frame-channel rows.
+// K2: scale, masking thresholds, quantiser (+ the raw-vs-compressed decision when a frame's
+// channels all sit in one wave).  A wavefront owns 4 consecutive frame-channel rows.
 //   phase 1  16 coefficients per lane and row: max|c| by shuffle (order-free), squares to LDS
 //   phase 2  band sums in the reference's ascending order (src/codec.rs:212-214): lane l sums
 //            bands (l & 15), +16, +32, +48 of row l >> 4, so the long last band (683 bins at
 //            48 kHz) of the 4 rows runs in 4 lanes side by side instead of one lane per wave
-//   phase 3  thresholds, noise floor, quantiser; dense i16 row + {scale, nnz} into the record
+//   phase 3  thresholds, noise floor, quantiser; {scale, nnz} into the record header
+//   phase 4  FUSED (1 / 2 / 4 channels: a frame's rows are 1 / 2 / 4 consecutive rows of this
+//            wave): size estimate and decision of src/codec.rs:505-521; a compressed frame gets
+//            its dense i16 rows, a raw frame the channel-planar windowed i16 plane (:496-502, Q1)
+//            - K3 is not launched at all.  Other channel counts: dense rows here, decision in K3.
 // ------------------------------------------------------------------------------------------
 constexpr int kQRows = 4;  // rows per wave
 
+template <bool FUSED>
 __global__ __launch_bounds__(256) void k_quantize(DeviceTables tb, const float *__restrict__ coef,
                                                    unsigned M, unsigned ch, unsigned long long rec_bytes,
-                                                   unsigned long long hdr_bytes,
+                                                   unsigned long long hdr_bytes, PcmView pcm, long long frame_begin,
                                                    unsigned char *__restrict__ records) {
   __shared__ __attribute__((aligned(16))) float ssq[4][kQRows][kHopI];  // 64 KiB
   __shared__ float sbase[4][kQRows][64];
@@ -117,32 +121,29 @@ __global__ __launch_bounds__(256) void k_quantize(DeviceTables tb, const float *
         unsigned i = lo;
         // head: up to 3 bins until the index is 16-byte aligned
         for (; i < hi && (i & 3u); ++i) ss = add_rn(ss, sq[i]);
-        // body: 8 bins per step as two ds_read_b128, the next step's reads in flight while the
-        // current 8 adds (a dependent chain, the reference's order) execute; ping-pong registers
-        if (i + 8 <= hi) {
+        // body: 16 bins per step as four ds_read_b128, the next step's reads in flight while the
+        // current 16 adds (a dependent chain, the reference's order) execute; ping-pong registers
+#define GLC_ADD4(V) ss = add_rn(ss, V.x); ss = add_rn(ss, V.y); ss = add_rn(ss, V.z); ss = add_rn(ss, V.w)
+        if (i + 16 <= hi) {
           const float4 *q4 = reinterpret_cast<const float4 *>(sq);
-          float4 a0 = q4[i >> 2], a1 = q4[(i >> 2) + 1];
-          while (i + 16 <= hi) {
-            const float4 b0 = q4[(i >> 2) + 2], b1 = q4[(i >> 2) + 3];
-            ss = add_rn(ss, a0.x); ss = add_rn(ss, a0.y); ss = add_rn(ss, a0.z); ss = add_rn(ss, a0.w);
-            ss = add_rn(ss, a1.x); ss = add_rn(ss, a1.y); ss = add_rn(ss, a1.z); ss = add_rn(ss, a1.w);
-            i += 8;
-            if (i + 16 <= hi) {
-              a0 = q4[(i >> 2) + 2];
-              a1 = q4[(i >> 2) + 3];
-              ss = add_rn(ss, b0.x); ss = add_rn(ss, b0.y); ss = add_rn(ss, b0.z); ss = add_rn(ss, b0.w);
-              ss = add_rn(ss, b1.x); ss = add_rn(ss, b1.y); ss = add_rn(ss, b1.z); ss = add_rn(ss, b1.w);
-              i += 8;
+          float4 a0 = q4[i >> 2], a1 = q4[(i >> 2) + 1], a2 = q4[(i >> 2) + 2], a3 = q4[(i >> 2) + 3];
+          while (i + 32 <= hi) {
+            const float4 b0 = q4[(i >> 2) + 4], b1 = q4[(i >> 2) + 5], b2 = q4[(i >> 2) + 6], b3 = q4[(i >> 2) + 7];
+            GLC_ADD4(a0); GLC_ADD4(a1); GLC_ADD4(a2); GLC_ADD4(a3);
+            i += 16;
+            if (i + 32 <= hi) {
+              a0 = q4[(i >> 2) + 4]; a1 = q4[(i >> 2) + 5]; a2 = q4[(i >> 2) + 6]; a3 = q4[(i >> 2) + 7];
+              GLC_ADD4(b0); GLC_ADD4(b1); GLC_ADD4(b2); GLC_ADD4(b3);
+              i += 16;
             } else {
-              a0 = b0;
-              a1 = b1;
+              a0 = b0; a1 = b1; a2 = b2; a3 = b3;
             }
           }
-          ss = add_rn(ss, a0.x); ss = add_rn(ss, a0.y); ss = add_rn(ss, a0.z); ss = add_rn(ss, a0.w);
-          ss = add_rn(ss, a1.x); ss = add_rn(ss, a1.y); ss = add_rn(ss, a1.z); ss = add_rn(ss, a1.w);
-          i += 8;
+          GLC_ADD4(a0); GLC_ADD4(a1); GLC_ADD4(a2); GLC_ADD4(a3);
+          i += 16;
         }
-        for (; i < hi; ++i) ss = add_rn(ss, sq[i]);  // tail: fewer than 8 bins
+#undef GLC_ADD4
+        for (; i < hi; ++i) ss = add_rn(ss, sq[i]);  // tail: fewer than 16 bins
         const float energy = sqrtf(ss / tb.band_len[b]);                                  // :214-215
         sbase[w][r][b] = mul_rn(mul_rn(mul_rn(energy, 0.01f), tb.cf), tb.band_pf[b]);      // :223
       }
@@ -150,13 +151,13 @@ __global__ __launch_bounds__(256) void k_quantize(DeviceTables tb, const float *
   }
   __syncthreads();
 
+  short4 pk[kQRows][4];
+  unsigned nnz[kQRows];
 #pragma unroll
   for (int r = 0; r < kQRows; ++r) {
     const unsigned m = m0 + r;
+    nnz[r] = 0;
     if (m >= M) break;
-    const unsigned frame = m / ch, c = m % ch;
-    unsigned char *rec = records + static_cast<size_t>(frame) * rec_bytes;
-    short *qrow = reinterpret_cast<short *>(rec + hdr_bytes) + static_cast<size_t>(c) * kFrameI;
     const float sc = scale[r];
     const float nfl = mul_rn(tb.noise_floor, sc);  // :277
     const float peak_gate = mul_rn(sc, 0.3f);      // global_max * 0.3, :232
@@ -164,7 +165,6 @@ __global__ __launch_bounds__(256) void k_quantize(DeviceTables tb, const float *
     unsigned cnt = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int k0 = (lane + 64 * j) * 4;
       const float cv[4] = {c4[r][j].x, c4[r][j].y, c4[r][j].z, c4[r][j].w};
       const float iv[4] = {indiv4[j].x, indiv4[j].y, indiv4[j].z, indiv4[j].w};
       short qv[4];
@@ -182,15 +182,50 @@ __global__ __launch_bounds__(256) void k_quantize(DeviceTables tb, const float *
         qv[e] = q;
         cnt += (q != 0);
       }
-      short4 pk;
-      pk.x = qv[0]; pk.y = qv[1]; pk.z = qv[2]; pk.w = qv[3];
-      *reinterpret_cast<short4 *>(qrow + k0) = pk;
+      pk[r][j].x = qv[0]; pk[r][j].y = qv[1]; pk[r][j].z = qv[2]; pk[r][j].w = qv[3];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    nnz[r] = cnt;
     if (lane == 0) {
+      const unsigned frame = m / ch, c = m % ch;
+      unsigned char *rec = records + static_cast<size_t>(frame) * rec_bytes;
       *reinterpret_cast<float *>(rec + 8 + 8 * c) = sc;
       *reinterpret_cast<unsigned *>(rec + 8 + 8 * c + 4) = cnt;
+    }
+  }
+
+  // phase 4: payload.  FUSED: the frame of row r spans rows r - r % ch .. + ch - 1 of this wave.
+#pragma unroll
+  for (int r = 0; r < kQRows; ++r) {
+    const unsigned m = m0 + r;
+    if (m >= M) break;
+    const unsigned frame = m / ch, c = m % ch;
+    unsigned char *rec = records + static_cast<size_t>(frame) * rec_bytes;
+    bool use_raw = false;
+    if (FUSED) {
+      unsigned long long compressed = 8ull + 4ull * ch + 64ull;   // :513, :515
+#pragma unroll
+      for (int q = 0; q < kQRows; ++q)
+        if (static_cast<unsigned>(q) / ch == static_cast<unsigned>(r) / ch) compressed += 8ull + 4ull * nnz[q];  // :507-511
+      const unsigned long long raw_size = 2ull * kFrameI * ch;    // :518
+      use_raw = static_cast<float>(compressed) >= mul_rn(static_cast<float>(raw_size), 0.85f);  // :521
+      if (c == 0 && lane == 0) {
+        *reinterpret_cast<unsigned *>(rec) = use_raw ? 1u : 0u;
+        *reinterpret_cast<unsigned *>(rec + 4) = 0u;
+      }
+    }
+    short *qrow = reinterpret_cast<short *>(rec + hdr_bytes) + static_cast<size_t>(c) * kFrameI;
+    if (!use_raw) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<short4 *>(qrow + (lane + 64 * j) * 4) = pk[r][j];
+    } else {
+      // raw fallback plane of this row's channel, windowed once (:498-502)
+      const long long fabs_ = frame_begin + frame;
+      for (int i = lane; i < kFrameI; i += 64) {
+        const float sw = mul_rn(pcm_at(pcm, fabs_, c, i), tb.window[i]);  // :500
+        qrow[i] = sat_i16(mul_rn(sw, 32767.0f));                          // :501
+      }
     }
   }
 }
@@ -295,39 +330,74 @@ __global__ __launch_bounds__(256) void k_imdct_rows(DeviceTables tb, DecodeRows 
 }
 
 // ------------------------------------------------------------------------------------------
-// D1, grouped: one workgroup decodes G consecutive rows (the channels of a frame and its
-// neighbours in time) over the UNION of their coefficient indices, so that a table row is read
-// from L2 once for the group instead of once per row - stereo pairs and consecutive frames of
-// tonal material share most of their indices.  Per row the arithmetic is unchanged: its stored
-// non-zeros are applied in ascending k; a row that lacks an index of the union skips it (a
-// wave-uniform branch), which is the same identity the sparse skip already relies on.
-//   LDS: dense coefficients [k][G] (zero = absent), a 1024-bit union map, the compacted union list
+// D1, SHIPPED: one workgroup decodes G consecutive frames of ONE channel (rows f*ch + c,
+// f = f0 .. f0+G-1) over the UNION of their coefficient indices, so that a table row is read from
+// L2 once for the group.  Consecutive frames of one channel are the rows that share indices:
+// tonal material keeps its partials from frame to frame, while two channels may carry different
+// instruments.  Per row the arithmetic is the reference's: its non-zeros applied in ascending k.
+//
+//   dense path  (the union is at most 3x the mean list): EVERY row of the group takes every union
+//               entry, branch-free - a row that lacks the index multiplies by its +0.0 and adds the
+//               signed zero, which is the identity on a running sum that is never -0.0 (the same
+//               identity the sparse skip rests on).  The entry step is hand-scheduled like K1's:
+//               4 x {8 v_pk_mul_f32, 8 v_pk_add_f32} with dependent instructions 8 apart, the table
+//               row of the next entry already in flight (global_load_dwordx4 issued one whole
+//               entry ahead, retired by a counted vmcnt), coefficients and union indices by
+//               broadcast ds_reads under counted lgkmcnt waits (tools/d1_tune.hip has the
+//               measurements behind these choices).
+//   sparse path (little sharing, e.g. transients): per (entry, row) wave-uniform skip, compiler-
+//               scheduled - the round-1 kernel's loop.
+//   LDS: dense coefficients [k][G] (zero = absent), a 1024-bit union map, the ascending union list.
+// `mode`: 0 = choose per group; 2 / 3 force the sparse / dense path (soak tools, glc_debug.h).
 // ------------------------------------------------------------------------------------------
+typedef float d1x2 __attribute__((ext_vector_type(2)));
+typedef float d1x4 __attribute__((ext_vector_type(4)));
+
+// table row k, this lane's 2 x 4 outputs: T[k][4 tid ..] and T[k][1024 + 4 tid ..]; `base` is
+// biased by +2048 B so that both halves are within the 13-bit signed instruction offset
+__device__ __forceinline__ void d1_issue_table(d1x4 &lo, d1x4 &hi, unsigned voff, const float *base) {
+  asm volatile(
+      "global_load_dwordx4 %0, %2, %3 offset:-2048\n\t"
+      "global_load_dwordx4 %1, %2, %3 offset:2048"
+      : "=&v"(lo), "=&v"(hi)
+      : "v"(voff), "s"(base)
+      : "memory");
+}
 template <int G>
-__global__ __launch_bounds__(256) void k_imdct_group(DeviceTables tb, DecodeRows rows, unsigned row_begin,
-                                                      unsigned M, unsigned ch, float *__restrict__ blocks) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_imdct_chan(DeviceTables tb, DecodeRows rows, unsigned row_begin, unsigned n_frames, unsigned ch, int mode,
+                  float *__restrict__ blocks) {
+  static_assert(G == 8, "the entry step is written for 8 rows (4 coefficient pairs)");
   __shared__ __attribute__((aligned(16))) float s_c[kHopI * G];
   __shared__ unsigned s_mask[kHopI / 32];
-  __shared__ unsigned short s_u[kHopI];
+  __shared__ unsigned short s_u[kHopI + 8];
   __shared__ unsigned s_wsum[4];
   const int tid = threadIdx.x;
-  const unsigned r0 = blockIdx.x * G;
+  // block -> (frame group, channel): workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8),
+  // and channels can differ in how many coefficients they keep, so every XCD takes frame groups of
+  // ALL channels: block 8 q + x handles channel q % ch of frame group (q / ch) * 8 + x.  The grid is
+  // padded to a multiple of 8 groups; surplus blocks leave at once.  (Speed only, never results.)
+  const unsigned q_ = blockIdx.x >> 3;
+  const unsigned c = q_ % ch;
+  const unsigned fr0 = ((q_ / ch) * 8u + (blockIdx.x & 7u)) * G;  // first frame of the group, relative to the launch
+  if (fr0 >= n_frames) return;
 
   for (int i = tid; i < kHopI * G; i += 256) s_c[i] = 0.0f;
   if (tid < kHopI / 32) s_mask[tid] = 0u;
   __syncthreads();
 
-  unsigned live = 0;  // rows of the group that take the transform path (uniform)
+  unsigned live = 0;   // rows of the group that take the transform path (uniform)
+  unsigned total = 0;  // their list lengths (uniform)
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    const unsigned r = r0 + g;
-    if (r >= M) continue;
+    const unsigned fr = fr0 + g;
+    if (fr >= n_frames) continue;
+    const unsigned r = fr * ch + c;
     const unsigned m = row_begin + r;
     const long long raw_off = rows.row_raw[m];
     if (raw_off >= 0) {
       // raw frame: read as if interleaved (Q1), /32767, no window (Q2) - src/codec.rs:629-640
       float *out = blocks + static_cast<size_t>(r) * kFrameI;
-      const unsigned c = m % ch;
       const unsigned long long raw_len = rows.row_raw_len[m];
       const short *raw = rows.raw_pool + raw_off;
       for (int i = tid; i < kFrameI; i += 256) {
@@ -341,6 +411,7 @@ __global__ __launch_bounds__(256) void k_imdct_group(DeviceTables tb, DecodeRows
     live |= 1u << g;
     const unsigned long long p0 = rows.row_begin[m];
     const unsigned n = min(rows.row_cnt[m], static_cast<unsigned>(kHopI));  // canonical lists hold <= 1024
+    total += n;
     const float scale = fmaxf(rows.row_scale[m], 1e-12f);                  // :653
     for (unsigned j = tid; j < n; j += 256) {
       const unsigned pr = rows.pairs[p0 + j];
@@ -381,53 +452,111 @@ __global__ __launch_bounds__(256) void k_imdct_group(DeviceTables tb, DecodeRows
   }
   __syncthreads();
   if (!live) return;
+  // the dense loop prefetches up to 4 entries past the end: give it valid indices to fetch
+  if (tid < 8) s_u[n_u + tid] = n_u ? s_u[n_u - 1] : static_cast<unsigned short>(0);
+  __syncthreads();
 
-  // packed f32 lanes (v_pk_mul_f32 / v_pk_add_f32: separately rounded, two outputs per issue slot)
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  f32x2 acc[G][4];
+  d1x2 acc[G][4];
 #pragma unroll
   for (int g = 0; g < G; ++g)
 #pragma unroll
-    for (int h = 0; h < 4; ++h) acc[g][h] = f32x2{0.f, 0.f};
-  const float *T = tb.cos + tid * 4;
-  f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
-  unsigned k = 0;
-  if (n_u) {
-    k = s_u[0];
-    const float *trow = T + static_cast<size_t>(k) * kFrameI;
-    t0 = *reinterpret_cast<const f32x4 *>(trow);
-    t1 = *reinterpret_cast<const f32x4 *>(trow + 1024);
-  }
-#pragma unroll 2
-  for (unsigned j = 0; j < n_u; ++j) {
-    // the next table row is in flight while this one is applied (the last step re-reads its own)
-    const unsigned kn = s_u[j + 1 < n_u ? j + 1 : j];
-    const float *nrow = T + static_cast<size_t>(kn) * kFrameI;
-    const f32x4 n0 = *reinterpret_cast<const f32x4 *>(nrow);
-    const f32x4 n1 = *reinterpret_cast<const f32x4 *>(nrow + 1024);
-    float cg[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) cg[g] = s_c[k * G + g];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const float cv = cg[g];
-      if (cv != 0.0f) {  // same value in every lane: the branch is wave-uniform
-        const f32x2 c2 = {cv, cv};
-        acc[g][0] = acc[g][0] + c2 * t0.xy;
-        acc[g][1] = acc[g][1] + c2 * t0.zw;
-        acc[g][2] = acc[g][2] + c2 * t1.xy;
-        acc[g][3] = acc[g][3] + c2 * t1.zw;
-      }
+    for (int h = 0; h < 4; ++h) acc[g][h] = d1x2{0.f, 0.f};
+
+  const bool dense = mode == 3 || (mode != 2 && n_u * G <= 3u * total);  // uniform
+  if (dense) {
+    const float *tbase = tb.cos + 512;  // +2048 B, see d1_issue_table
+    const unsigned lane_off = static_cast<unsigned>(tid) * 16u;
+    const unsigned c_lds = static_cast<unsigned>(reinterpret_cast<uintptr_t>(&s_c[0]));
+    const unsigned u_lds = static_cast<unsigned>(reinterpret_cast<uintptr_t>(&s_u[0]));
+    // Registers: two table slots (the entry being applied and the next one, in flight), ONE set of
+    // the 8 coefficients (each half is re-read for the next entry right after the two row pairs that
+    // consumed it), two union indices ahead.
+    d1x4 t_lo[2], t_hi[2], clo, chi;
+    unsigned kq[2];  // at step j: union indices of entries j+1 and j+2 (rotating)
+    d1_issue_table(t_lo[0], t_hi[0], (static_cast<unsigned>(s_u[0]) << 13) + lane_off, tbase);
+    d1_issue_table(t_lo[1], t_hi[1], (static_cast<unsigned>(s_u[1]) << 13) + lane_off, tbase);
+    kq[0] = s_u[1];
+    kq[1] = s_u[2];
+    {
+      const unsigned a0 = c_lds + (static_cast<unsigned>(s_u[0]) << 5);
+      asm volatile(
+          "ds_read_b128 %0, %2\n\t"
+          "ds_read_b128 %1, %2 offset:16\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(clo), "=&v"(chi)
+          : "v"(a0)
+          : "memory");
     }
-    t0 = n0, t1 = n1, k = kn;
+    // One entry.  S: table slot of entry J; XC: register with index J+1 (whose coefficients this step
+    // prefetches); XR: register with index J+2 (whose table row refills slot S).  On entry the LDS
+    // reads still in flight are the previous step's [index, clo, chi], of the vector-memory loads
+    // only the two of entry J+1 may be outstanding.
+#define GLC_D1_STEP(S, XC, XR, J)                                                                               \
+  do {                                                                                                          \
+    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(1)"                                                                \
+                 : "+v"(t_lo[S]), "+v"(t_hi[S]), "+v"(clo), "+v"(kq[XC]), "+v"(kq[XR])::"memory");               \
+    const unsigned caddr = c_lds + (kq[XC] << 5);                                                               \
+    asm volatile("ds_read_u16 %0, %1" : "=&v"(kq[XC]) : "v"(u_lds + 2u * ((J) + 3u)) : "memory");               \
+    k1::mac2rows(acc[0], acc[1], clo.xy, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);                        \
+    k1::mac2rows(acc[2], acc[3], clo.zw, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);                        \
+    asm volatile("ds_read_b128 %0, %2\n\ts_waitcnt lgkmcnt(2)" : "=&v"(clo), "+v"(chi) : "v"(caddr) : "memory"); \
+    k1::mac2rows(acc[4], acc[5], chi.xy, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);                        \
+    k1::mac2rows(acc[6], acc[7], chi.zw, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);                        \
+    asm volatile("ds_read_b128 %0, %1 offset:16" : "=&v"(chi) : "v"(caddr) : "memory");                         \
+    d1_issue_table(t_lo[S], t_hi[S], (kq[XR] << 13) + lane_off, tbase);                                         \
+  } while (0)
+    unsigned j = 0;
+#pragma unroll 1
+    for (; j + 2 <= n_u; j += 2) {
+      GLC_D1_STEP(0, 0, 1, j);
+      GLC_D1_STEP(1, 1, 0, j + 1);
+    }
+    if (j < n_u) GLC_D1_STEP(0, 0, 1, j);
+#undef GLC_D1_STEP
+    // drain the run-ahead loads before their registers are reused
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(t_lo[0]), "+v"(t_hi[0]), "+v"(t_lo[1]), "+v"(t_hi[1]), "+v"(clo), "+v"(chi), "+v"(kq[0]),
+                   "+v"(kq[1])::"memory");
+  } else {
+    const float *T = tb.cos + tid * 4;
+    d1x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+    unsigned k = 0;
+    if (n_u) {
+      k = s_u[0];
+      const float *trow = T + static_cast<size_t>(k) * kFrameI;
+      t0 = *reinterpret_cast<const d1x4 *>(trow);
+      t1 = *reinterpret_cast<const d1x4 *>(trow + 1024);
+    }
+#pragma unroll 2
+    for (unsigned j = 0; j < n_u; ++j) {
+      // the next table row is in flight while this one is applied (the padded list repeats the last)
+      const unsigned kn = s_u[j + 1];
+      const float *nrow = T + static_cast<size_t>(kn) * kFrameI;
+      const d1x4 n0 = *reinterpret_cast<const d1x4 *>(nrow);
+      const d1x4 n1 = *reinterpret_cast<const d1x4 *>(nrow + 1024);
+      float cg[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) cg[g] = s_c[k * G + g];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float cv = cg[g];
+        if (cv != 0.0f) {  // same value in every lane: the branch is wave-uniform
+          const d1x2 c2 = {cv, cv};
+          acc[g][0] = acc[g][0] + c2 * t0.xy;
+          acc[g][1] = acc[g][1] + c2 * t0.zw;
+          acc[g][2] = acc[g][2] + c2 * t1.xy;
+          acc[g][3] = acc[g][3] + c2 * t1.zw;
+        }
+      }
+      t0 = n0, t1 = n1, k = kn;
+    }
   }
   const float4 w0 = *reinterpret_cast<const float4 *>(tb.window + tid * 4);
   const float4 w1 = *reinterpret_cast<const float4 *>(tb.window + 1024 + tid * 4);
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     if (!(live & (1u << g))) continue;
-    float *out = blocks + static_cast<size_t>(r0 + g) * kFrameI;
+    float *out = blocks + static_cast<size_t>((fr0 + g) * ch + c) * kFrameI;
     float4 o0, o1;  // out[i] = s*norm (:388) then *= window[i] (:674)
     o0.x = mul_rn(mul_rn(acc[g][0].x, tb.norm), w0.x); o0.y = mul_rn(mul_rn(acc[g][0].y, tb.norm), w0.y);
     o0.z = mul_rn(mul_rn(acc[g][1].x, tb.norm), w0.z); o0.w = mul_rn(mul_rn(acc[g][1].y, tb.norm), w0.w);
@@ -628,25 +757,31 @@ hipError_t launch_mdct_forward(const DeviceTables &t, const PcmView &pcm, uint64
   // not by throughput: 32x64 tiles with 4x4 outputs per lane halve the work per step and spread
   // the rows over 16x more workgroups (0.13 ms against 0.19 ms at 172 rows, k1_tune 86 2).
   if (M <= 512) return k1::launch<32, 64, 32, 4, 4, 4, 2>(t, pcm, frame_begin, M, coef, s);
-  if (M < 4096) return k1::launch_sched<64, 128, 16, 4, 0, 4>(t, pcm, frame_begin, M, coef, s);  // short clips: more workgroups
+  if (M < 4096) return k1::launch_sched<64, 128, 16, 4>(t, pcm, frame_begin, M, coef, s);  // short clips: more workgroups
   // 512 threads, 4x8 per lane, table tile by LDS-DMA; PCM by one dwordx4 per lane and stage when the
   // channel count divides the tile height, else one dword per (row, sample)
   switch (pcm.ch) {
-    case 1: return k1::launch_dma<4, 0, 128, 1>(t, pcm, frame_begin, M, coef, s);
-    case 2: return k1::launch_dma<4, 0, 128, 2>(t, pcm, frame_begin, M, coef, s);
-    case 4: return k1::launch_dma<4, 0, 128, 4>(t, pcm, frame_begin, M, coef, s);
-    case 8: return k1::launch_dma<4, 0, 128, 8>(t, pcm, frame_begin, M, coef, s);
+    case 1: return k1::launch_dma<4, 1>(t, pcm, frame_begin, M, coef, s);
+    case 2: return k1::launch_dma<4, 2>(t, pcm, frame_begin, M, coef, s);
+    case 4: return k1::launch_dma<4, 4>(t, pcm, frame_begin, M, coef, s);
+    case 8: return k1::launch_dma<4, 8>(t, pcm, frame_begin, M, coef, s);
     default: return k1::launch_dma<4>(t, pcm, frame_begin, M, coef, s);
   }
 }
 
-hipError_t launch_quantize(const DeviceTables &t, const float *coef, uint32_t M, uint32_t ch,
-                           uint8_t *records, hipStream_t s) {
+hipError_t launch_quantize(const DeviceTables &t, const float *coef, uint32_t M, uint32_t ch, const PcmView &pcm,
+                           uint64_t frame_begin, uint8_t *records, hipStream_t s, bool *decided) {
+  *decided = ch == 1 || ch == 2 || ch == 4;  // a frame's rows sit in one wave: K2 decides raw-vs-compressed itself
   if (M == 0) return hipSuccess;
   const unsigned long long hdr = ((8ull + 8ull * ch) + 15ull) & ~15ull;
   const unsigned long long rec = hdr + 2ull * kFrameI * ch;
-  hipLaunchKernelGGL(k_quantize, dim3((M + 4 * kQRows - 1) / (4 * kQRows)), dim3(256), 0, s, t, coef, M, ch, rec, hdr,
-                     records);
+  const dim3 grid((M + 4 * kQRows - 1) / (4 * kQRows));
+  if (*decided)
+    hipLaunchKernelGGL(k_quantize<true>, grid, dim3(256), 0, s, t, coef, M, ch, rec, hdr, pcm,
+                       static_cast<long long>(frame_begin), records);
+  else
+    hipLaunchKernelGGL(k_quantize<false>, grid, dim3(256), 0, s, t, coef, M, ch, rec, hdr, pcm,
+                       static_cast<long long>(frame_begin), records);
   return hipGetLastError();
 }
 
@@ -688,17 +823,17 @@ hipError_t launch_compact(const uint8_t *records, uint32_t M, uint32_t ch, uint6
 }
 
 hipError_t launch_imdct_rows(const DeviceTables &t, const DecodeRows &rows, uint32_t row_begin,
-                             uint32_t M, uint32_t ch, float *blocks, hipStream_t s) {
+                             uint32_t M, uint32_t ch, float *blocks, hipStream_t s, int variant) {
   if (M == 0) return hipSuccess;
-  // tuning / cross-check knob, read per launch: rows per workgroup (0 = the one-row kernel)
-  const char *group_env = std::getenv("GLC_D1_GROUP");
-  const int group = group_env ? std::atoi(group_env) : 8;
-  switch (group) {
-    case 0: hipLaunchKernelGGL(k_imdct_rows, dim3(M), dim3(256), 0, s, t, rows, row_begin, M, ch, blocks); break;
-    case 2: hipLaunchKernelGGL(k_imdct_group<2>, dim3((M + 1) / 2), dim3(256), 0, s, t, rows, row_begin, M, ch, blocks); break;
-    case 4: hipLaunchKernelGGL(k_imdct_group<4>, dim3((M + 3) / 4), dim3(256), 0, s, t, rows, row_begin, M, ch, blocks); break;
-    default: hipLaunchKernelGGL(k_imdct_group<8>, dim3((M + 7) / 8), dim3(256), 0, s, t, rows, row_begin, M, ch, blocks); break;
+  // every caller decodes whole frames; the one-row kernel is the cross-check variant (glc_debug.h)
+  if (variant == 1 || ch == 0 || M % ch != 0) {
+    hipLaunchKernelGGL(k_imdct_rows, dim3(M), dim3(256), 0, s, t, rows, row_begin, M, ch, blocks);
+    return hipGetLastError();
   }
+  const uint32_t n_frames = M / ch;
+  const uint32_t groups = (n_frames + 7) / 8;
+  hipLaunchKernelGGL(k_imdct_chan<8>, dim3(((groups + 7) / 8) * 8 * ch), dim3(256), 0, s, t, rows, row_begin, n_frames, ch,
+                     variant, blocks);
   return hipGetLastError();
 }
 

@@ -1,0 +1,28 @@
+/*
+ * glc_debug.h - cross-check hooks of libglc_hip.so.  NOT part of the drop-in boundary (that is
+ * include/glc.h): these entry points exist so that soak tools and tests can run one stream through
+ * two independent implementations of the same arithmetic and demand identical bits.
+ */
+#ifndef GLC_DEBUG_H
+#define GLC_DEBUG_H
+
+#include "glc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Which inverse-transform kernel the decode entry points of `ctx` launch (imdct_block,
+ * src/codec.rs:377-390):
+ *   0  shipped: k_imdct_chan<8> (8 frames of one channel per workgroup, dense or sparse path chosen
+ *      per group)
+ *   1  k_imdct_rows: one row per workgroup, no grouping (the simplest restatement)
+ *   2  k_imdct_chan<8> forced onto its sparse path (per-row skip of absent indices)
+ *   3  k_imdct_chan<8> forced onto its dense path (every row takes every union entry)
+ * All four produce the same bits; tools/soak_decode.py checks that on random streams. */
+int glc_debug_set_imdct_variant(glc_ctx *ctx, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLC_DEBUG_H */

@@ -314,26 +314,96 @@ def test_cfg3_ten_minutes_roundtrip(torch_cuda):
         assert np.array_equal(bits(a), bits(b))
 
 
-def test_cfg4_long_96k_stream_shard(torch_cuda):
-    """config 4 (one rank's share): a long 96 kHz stereo stream built by tiling a 60 s segment.
-    60 s * 96000 = 5625 frames exactly, so frame records repeat with period 5625 — a checksum-free,
-    size-independent property — and the first period is pinned against the oracle on a prefix."""
+def _blocks_of_frame(fr, ch):
+    """Windowed IMDCT blocks [ch][2048] of one EncodedFrame, by the oracle's imdct_block
+    (src/codec.rs:626-675): what the overlap-add consumes."""
+    _, w, _ = O.tables()
+    out = np.zeros((ch, 2048), np.float32)
+    for c in range(ch):
+        if fr.raw_pcm is not None:
+            idx = np.arange(2048) * ch + c
+            ok = idx < fr.raw_pcm.size
+            out[c, ok] = fr.raw_pcm[idx[ok]].astype(np.float32) / np.float32(32767.0)
+            continue
+        coeffs = np.zeros(1024, np.float32)
+        scale = np.maximum(np.float32(fr.scale_factors[c]), np.float32(1e-12))
+        for k, q in fr.sparse_coeffs_per_channel[c]:
+            if k < 1024:
+                coeffs[k] = (np.float32(q) / np.float32(32768.0)) * scale
+        out[c] = O.imdct_block(coeffs) * w
+    return out
+
+
+def test_cfg4_one_hour_96k_stereo_true_size(torch_cuda):
+    """BASELINE config 4, one rank's share AT TRUE SIZE: 1 h of 96 kHz stereo = 691 200 000 samples,
+    337 500 frames (2.76 GB of f32 PCM, 2.77 GB of records).  The stream is a 60 s segment tiled 60
+    times; 60 s x 96 kHz = 5625 frames exactly, so records and decoded PCM repeat with period 5625
+    frames - a size-independent property checked over the whole hour - and a 64-frame window near
+    frame 337 000 (per-channel sample offsets beyond 2^28, byte offsets beyond 2 GiB: 64-bit index
+    arithmetic and the buffer-descriptor rebasing of K1) is pinned against the oracle, for the
+    encoder's records and for the decoded PCM."""
     sr, ch = 96000, 2
     seg = gen_chord(sr, ch, 60 * sr, n_tones=8)
-    reps = 6                                     # 6 min per rank here; 1 h in the real config
+    reps = 60
     x = _tile(seg, ch, reps)
+    assert x.size == 691_200_000
     plan = glc_amd.plan_encode(x.size, ch)
-    assert plan.n_frames == 5625 * reps
-    recs, _ = device_encode(torch_cuda, x, sr, ch, want_coeffs=False)
+    nf = plan.n_frames
+    assert nf == 337_500 == 5625 * reps
     rec = glc_amd.lib.glc_record_bytes(ch)
-    r = recs.reshape(-1, rec)
-    for k in range(1, reps):
-        assert np.array_equal(r[1:5624], r[k * 5625 + 1:k * 5625 + 5624])
-    ref = O.encode(x[:(64 * 1024 + 512) * ch], sr, ch, taps=True)
-    is_raw, scale, nnz, payload = split_records(recs[:64 * rec], ch)
-    assert np.array_equal(bits(scale[:62 * ch]), bits(ref.scales[:62 * ch]))
-    assert np.array_equal(nnz[:62 * ch], ref.nnz[:62 * ch])
-    assert np.array_equal(payload[:62, :, :1024].reshape(-1, 1024), ref.dense_q[:62 * ch])
+    d_pcm = torch_cuda.from_numpy(x).cuda()
+    d_rec = torch_cuda.zeros(nf * rec, dtype=torch_cuda.uint8, device="cuda")
+    enc = glc_amd.Encoder(sr)
+    torch_cuda.cuda.synchronize()
+    enc.encode_range_device(d_pcm.data_ptr(), 0, plan.per_channel, x.size, ch, 0, nf, d_rec.data_ptr())
+    enc.synchronize()
+    r = d_rec.view(nf, rec)
+    for k in range(1, reps):   # periodicity over the whole hour, compared on the device
+        assert torch_cuda.equal(r[1:5624], r[k * 5625 + 1:k * 5625 + 5624]), f"period {k}"
+    # far-end window pinned against the oracle, computed from that window's own PCM slice
+    f0, f1 = 337_000, 337_064
+    t0, t1 = f0 * 1024 - 512, min(plan.per_channel, (f1 - 1) * 1024 - 512 + 2048)
+    assert t0 * ch * 4 > 2 ** 31
+    want, _ = O.encode_range_records(x[t0 * ch:t1 * ch], t0, t1 - t0, x.size, sr, ch, f0, f1)
+    got = r[f0:f1].reshape(-1).cpu().numpy()
+    assert np.array_equal(got, want)
+    # and the stream's last frames (zero padding past the end of a > 2^31-element buffer)
+    want, _ = O.encode_range_records(x[(nf - 9) * 1024 * ch:], (nf - 9) * 1024, plan.per_channel - (nf - 9) * 1024,
+                                     x.size, sr, ch, nf - 8, nf)
+    assert np.array_equal(r[nf - 8:nf].reshape(-1).cpu().numpy(), want)
+    # EncodedAudio through the device compaction (scan offsets beyond 2^32 bytes of records)
+    ea = enc.frames_from_device_records(d_rec.data_ptr(), nf, x.size, ch)
+    info = ea.info()
+    assert info.n_frames == nf and info.n_raw_frames == 0 and info.total_nnz > nf
+    del d_rec, r, d_pcm
+    # decode: exact length, periodicity, and the far-end window against blocks from the oracle's IMDCT
+    dec = glc_amd.Decoder(ch, sr).decode(ea)
+    assert dec.size == x.size
+    per = 5625 * 1024 * ch
+    for k in (1, 7, 31, 57):   # (the 60th period ends in the stream's tail)
+        assert np.array_equal(bits(dec[per:2 * per]), bits(dec[(k + 1) * per:(k + 2) * per])), f"decoded period {k}"
+    blocks = {f: _blocks_of_frame(ea.frames[f], ch) for f in range(f0, f0 + 13)}
+    for h in range(f0 + 1, f0 + 13):   # hop h = second half of frame h-1 + first half of frame h (:688-705)
+        hop = (blocks[h - 1][:, 1024:] + blocks[h][:, :1024]).T.reshape(-1)      # interleaved
+        a = h * 1024 * ch - 512                                                   # delay trim in interleaved units (Q3)
+        assert np.array_equal(bits(dec[a:a + 1024 * ch]), bits(hop)), f"decoded hop {h}"
+    assert calculate_snr(x[:400000], dec[:400000]) > -10.0
+
+
+def test_multi_gpu_host_tool(torch_cuda):
+    """tools/glc_multi_gpu.cpp: one process, one context per visible device, RCCL gather of the
+    compact blobs to device 0, bytes compared with the single-device encode inside the tool (with one
+    visible device the collective is empty).  Both shardings of SURVEY 8e."""
+    import subprocess
+    exe = os.path.join(ROOT, "build", "glc_multi_gpu")
+    if not os.path.exists(exe):
+        import __graft_entry__
+        __graft_entry__.build_tools()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for args in (["--frames", "700"], ["--streams", "--frames", "300"]):
+        p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300, env=env)
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert "OK: every assembled stream is byte-identical" in p.stdout
 
 
 def test_cfg5_eight_channel_192k(torch_cuda):

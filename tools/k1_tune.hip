@@ -1,7 +1,7 @@
 // k1_tune.hip — times tile-shape variants of the forward-MDCT kernel (glc_mdct_fwd.hpp) against
 // each other on the GPU and checks every variant bit-for-bit against a naive one-output-per-lane
 // kernel that accumulates in the reference's order.  Development tool, not part of the library.
-// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I gapless-lossy-codec_amd/csrc \
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -I gapless-lossy-codec_amd/csrc -I tools \
 //        tools/k1_tune.hip -o build/k1_tune
 #include <hip/hip_runtime.h>
 
@@ -13,7 +13,8 @@
 #include <string>
 #include <vector>
 
-#include "glc_mdct_fwd.hpp"
+#include "glc_mdct_fwd.hpp"  // namespace glc::k1: the kernels the library ships
+#include "k1_variants.hpp"   // namespace glc::k1x: every other shape / schedule / ablation (tuning only)
 
 #pragma clang fp contract(off)
 
@@ -56,7 +57,7 @@ struct Variant {
 };
 
 #define V(BM, BN, BK, TM, TN, UN, MW) \
-  Variant { #BM "x" #BN " bk" #BK " t" #TM "x" #TN " u" #UN " w" #MW, k1::launch<BM, BN, BK, TM, TN, UN, MW> }
+  Variant { #BM "x" #BN " bk" #BK " t" #TM "x" #TN " u" #UN " w" #MW, k1x::launch<BM, BN, BK, TM, TN, UN, MW> }
 
 __global__ void k_fill_random(float *p, size_t n, unsigned seed) {
   for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) {
@@ -119,7 +120,7 @@ int main(int argc, char **argv) {
     for (int r = 0; r < reps; ++r) {
       hipLaunchKernelGGL(k_fill_random, dim3(1024), dim3(256), 0, 0, d_pcm, n_samples, 0x9E3779B9u * (unsigned)(r + 1));
       hipLaunchKernelGGL(k_naive, dim3(4, M), dim3(256), 0, 0, tb, pcm, 0ll, M, d_ref);
-      const hipError_t launched = (r & 1) ? (ch == 2 ? k1::launch_dma<4, 0, 128, 2>(tb, pcm, 0, M, d_out, 0) : k1::launch_dma<4>(tb, pcm, 0, M, d_out, 0))
+      const hipError_t launched = (r & 1) ? (ch == 2 ? k1::launch_dma<4, 2>(tb, pcm, 0, M, d_out, 0) : k1::launch_dma<4>(tb, pcm, 0, M, d_out, 0))
                              : k1::launch_dma<4>(tb, pcm, 0, M, d_out, 0);
       CHECK(launched);
       hipLaunchKernelGGL(k_count_diff, dim3(1024), dim3(256), 0, 0, reinterpret_cast<const unsigned *>(d_ref),
@@ -140,28 +141,34 @@ int main(int argc, char **argv) {
 
   // hand-scheduled kernels (shipped shapes first), their ablations, then hipcc-scheduled shapes
   std::vector<Variant> vs = {
-      Variant{"sched pk 128x128 bk16 t4x8 w4 512thr (shipped, M < 16384)", k1::launch_sched<128, 128, 16, 4, 0, 4>},
-      Variant{"sched pk 128x128 bk16 t8x8 w3 256thr (shipped, M >= 16384)", k1::launch_sched<128, 128, 16, 3, 0, 8>},
-      Variant{"sched pk 128x128 bk16 t4x8 w4 512thr + window in LDS", k1::launch_sched<128, 128, 16, 4, 0, 4, false, 2, true>},
-      Variant{"sched pk 128x128 bk16 t8x8 w3 256thr + window in LDS", k1::launch_sched<128, 128, 16, 3, 0, 8, false, 2, true>},
-      Variant{"dma   pk 128x128 bk16 t4x8 w4 512thr ring3 (table by LDS-DMA)", k1::launch_dma<4>},
-      Variant{"dma   pk 128x128 ... w3", k1::launch_dma<3>},
-      Variant{"dma   pk 128x128 + segment loader (one dwordx4 per lane and stage)", k1::launch_dma<4, 0, 128, 2>},
-      Variant{"mx    128x128 bk16 256thr: products by v_mfma_f32_32x32x1_2b (C = 0), adds by VALU, w2", k1::launch_mx<16, 2>},
-      Variant{"mx    128x128 bk16 ... w3", k1::launch_mx<16, 3>},
-      Variant{"mx    128x128 bk16 ... w4", k1::launch_mx<16, 4>},
-      Variant{"mx    128x128 bk32 ... w2", k1::launch_mx<32, 2>},
-      Variant{"dma   pk  64x128 bk16 t4x8 w4 256thr ring3, window by scalar loads", k1::launch_dma<4, 0, 64>},
-      Variant{"dma   pk  64x128 ... w5", k1::launch_dma<5, 0, 64>},
-      Variant{"  512thr ABL1 (no staging, no barrier)", k1::launch_sched<128, 128, 16, 4, 1, 4>},
-      Variant{"  512thr ABL2 (pure VALU stream)", k1::launch_sched<128, 128, 16, 4, 2, 4>},
-      Variant{"  512thr ABL3 (staging, no barrier)", k1::launch_sched<128, 128, 16, 4, 3, 4>},
-      Variant{"  512thr ABL4 (barrier, no staging)", k1::launch_sched<128, 128, 16, 4, 4, 4>},
-      Variant{"sched pk  64x128 bk16 t4x8 w4 256thr", k1::launch_sched<64, 128, 16, 4, 0, 4>},
-      Variant{"sched pk  64x128 bk16 t4x8 w4 ring3", k1::launch_sched<64, 128, 16, 4, 0, 4, false, 3>},
-      Variant{"sched sc  64x128 bk16 t4x8 w4 (scalar v_mul/v_add)", k1::launch_sched<64, 128, 16, 4, 0, 4, true>},
-      Variant{"sched pk  64x128 bk8  t4x8 w4", k1::launch_sched<64, 128, 8, 4, 0, 4>},
-      Variant{"sched pk  64x128 bk32 t4x8 w4", k1::launch_sched<64, 128, 32, 4, 0, 4>},
+      // the three kernels libglc_hip.so ships (csrc/glc_mdct_fwd.hpp)
+      Variant{"SHIPPED dma 128x128 512thr, per-row PCM loader (>= 4096 rows, other channel counts)", k1::launch_dma<4>},
+      Variant{"SHIPPED dma 128x128 512thr, dwordx4 segment loader (>= 4096 rows, stereo)", k1::launch_dma<4, 2>},
+      Variant{"SHIPPED sched 64x128 256thr (513..4095 rows)", k1::launch_sched<64, 128, 16, 4>},
+      Variant{"SHIPPED hipcc-scheduled 32x64 t4x4 (<= 512 rows)", k1::launch<32, 64, 32, 4, 4, 4, 2>},
+      // tuning variants (tools/k1_variants.hpp)
+      Variant{"sched pk 128x128 bk16 t4x8 w4 512thr (shipped, M < 16384)", k1x::launch_sched<128, 128, 16, 4, 0, 4>},
+      Variant{"sched pk 128x128 bk16 t8x8 w3 256thr (shipped, M >= 16384)", k1x::launch_sched<128, 128, 16, 3, 0, 8>},
+      Variant{"sched pk 128x128 bk16 t4x8 w4 512thr + window in LDS", k1x::launch_sched<128, 128, 16, 4, 0, 4, false, 2, true>},
+      Variant{"sched pk 128x128 bk16 t8x8 w3 256thr + window in LDS", k1x::launch_sched<128, 128, 16, 3, 0, 8, false, 2, true>},
+      Variant{"dma   pk 128x128 bk16 t4x8 w4 512thr ring3 (table by LDS-DMA)", k1x::launch_dma<4>},
+      Variant{"dma   pk 128x128 ... w3", k1x::launch_dma<3>},
+      Variant{"dma   pk 128x128 + segment loader (one dwordx4 per lane and stage)", k1x::launch_dma<4, 0, 128, 2>},
+      Variant{"mx    128x128 bk16 256thr: products by v_mfma_f32_32x32x1_2b (C = 0), adds by VALU, w2", k1x::launch_mx<16, 2>},
+      Variant{"mx    128x128 bk16 ... w3", k1x::launch_mx<16, 3>},
+      Variant{"mx    128x128 bk16 ... w4", k1x::launch_mx<16, 4>},
+      Variant{"mx    128x128 bk32 ... w2", k1x::launch_mx<32, 2>},
+      Variant{"dma   pk  64x128 bk16 t4x8 w4 256thr ring3, window by scalar loads", k1x::launch_dma<4, 0, 64>},
+      Variant{"dma   pk  64x128 ... w5", k1x::launch_dma<5, 0, 64>},
+      Variant{"  512thr ABL1 (no staging, no barrier)", k1x::launch_sched<128, 128, 16, 4, 1, 4>},
+      Variant{"  512thr ABL2 (pure VALU stream)", k1x::launch_sched<128, 128, 16, 4, 2, 4>},
+      Variant{"  512thr ABL3 (staging, no barrier)", k1x::launch_sched<128, 128, 16, 4, 3, 4>},
+      Variant{"  512thr ABL4 (barrier, no staging)", k1x::launch_sched<128, 128, 16, 4, 4, 4>},
+      Variant{"sched pk  64x128 bk16 t4x8 w4 256thr", k1x::launch_sched<64, 128, 16, 4, 0, 4>},
+      Variant{"sched pk  64x128 bk16 t4x8 w4 ring3", k1x::launch_sched<64, 128, 16, 4, 0, 4, false, 3>},
+      Variant{"sched sc  64x128 bk16 t4x8 w4 (scalar v_mul/v_add)", k1x::launch_sched<64, 128, 16, 4, 0, 4, true>},
+      Variant{"sched pk  64x128 bk8  t4x8 w4", k1x::launch_sched<64, 128, 8, 4, 0, 4>},
+      Variant{"sched pk  64x128 bk32 t4x8 w4", k1x::launch_sched<64, 128, 32, 4, 0, 4>},
       V(128, 128, 16, 8, 8, 2, 2), V(128, 128, 8, 8, 8, 2, 2), V(64, 128, 16, 4, 8, 2, 4),
       V(128, 128, 16, 4, 8, 2, 2), V(64, 64, 16, 4, 4, 4, 8),
       // short clips (run with e.g. `k1_tune 86 2`): latency of the 2048-step chain, not throughput

@@ -1,4 +1,8 @@
-// glc_mdct_fwd.hpp — K1, the windowed forward MDCT as an exact-order SGEMM on the vector ALU.
+// k1_variants.hpp — TUNING ONLY (namespace glc::k1x): every shape, schedule and ablation of the
+// forward-MDCT kernel that was measured on the way to the shipped ones.  The library does not
+// include this file; csrc/glc_mdct_fwd.hpp (namespace glc::k1) holds exactly the kernels
+// libglc_hip.so instantiates.  tools/k1_tune.hip times these against the shipped kernels and
+// checks all of them bit for bit against a naive kernel.
 //
 //   C[m][k] = fl( fl( sum_{i ascending} fl( fl(x[m,i]*w[i]) * T[k][i] ) ) * norm )
 //
@@ -7,28 +11,32 @@
 // K = 2048; the K loop is strictly ascending with ONE accumulator per output, multiply and add
 // are separate instructions (v_pk_mul_f32 / v_pk_add_f32, never an FMA), there is no split-K.
 //
-// What is in this file - exactly the kernels libglc_hip.so instantiates (launch_mdct_forward in
-// glc_kernels.hip); every other shape, schedule and ablation that was measured lives in
-// tools/k1_variants.hpp beside the tuning harness tools/k1_tune.hip:
-//   k_mdct_fwd_dma     launches of >= 4096 rows (BASELINE config 2 = 8192): 128x128 tile, 512 threads,
-//                      4x8 outputs per lane, table tile copied global -> LDS by LDS-DMA two stages ahead
-//                      (3-slot ring), one counted vmcnt wait per stage; PCM tile by one dwordx4 per lane
-//                      and stage when the stream has 1 / 2 / 4 / 8 channels (CH), one dword per
-//                      (row, sample) otherwise (CH = 0).
-//   k_mdct_fwd_sched   513..4095 rows, as <64,128,16,4>: 64x128 tile, 256 threads, hand-scheduled
-//                      inline-asm i-steps (step4), LDS operand prefetch, XCD-aware tile map, register
-//                      staging, classic double buffer.
-//   k_mdct_fwd         up to 512 rows, as <32,64,32,4,4,4,2>: the same tiling left to hipcc's scheduler
-//                      (short clips: the latency of one workgroup's 2048-step chain is everything, and
-//                      smaller lane tiles shorten the step).
-//   mac2rows           the 2-row x 8-column multiply/add block; also the entry step of D1 (k_imdct_chan).
+// What is in this file
+//   k_mdct_fwd_dma     SHIPPED for launches of >= 4096 rows (BASELINE config 2 = 8192): 128x128 tile,
+//                      512 threads, 4x8 outputs per lane, table tile copied global -> LDS by LDS-DMA
+//                      two stages ahead (3-slot ring), one counted vmcnt wait per stage; PCM tile by
+//                      one dwordx4 per lane and stage when the stream has 1 / 2 / 4 / 8 channels
+//                      (CH), one dword per (row, sample) otherwise.  BM = 64 (256 threads, window by
+//                      scalar loads) is a measured alternative, not shipped.
+//   k_mdct_fwd_sched   SHIPPED for 513..4095 rows as <64,128,16,4,0,4>.  Hand-scheduled inline-asm
+//                      i-steps (step4 / mac2rows), LDS operand prefetch, XCD-aware tile map, register
+//                      staging.  Other shapes and ABL / SCALAR / RING / WLDS are tuning knobs.
+//   k_mdct_fwd         the same tiling left to hipcc's scheduler.  SHIPPED as <32,64,32,4,4,4,2> for
+//                      launches of up to 512 rows (short clips: the latency of one workgroup's
+//                      2048-step chain is everything, and smaller lane tiles shorten the step);
+//                      larger shapes are tuning only (19-24 T MAC/s).
+//   k_mdct_fwd_mx      tuning only: products by v_mfma_f32_32x32x1_2b_f32 with C = 0 (bit-identical to
+//                      v_mul_f32, tools/mfma_probe.hip), accumulation by v_pk_add_f32.  Bit-exact,
+//                      slower: the f32 matrix instruction runs on the vector ALU's multipliers.
+// tools/k1_tune.hip times them against each other and checks every variant bit-for-bit against a
+// naive kernel; profiles/r01_k1_tune_*.txt hold the numbers.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include "glc_kernels.h"
 
 namespace glc {
-namespace k1 {
+namespace k1x {
 
 constexpr int kHopI = 1024;
 constexpr int kFrameI = 2048;
@@ -199,23 +207,23 @@ __global__ __launch_bounds__((BM / TM) * (BN / TN), MINW) void k_mdct_fwd(Device
 }
 
 // ------------------------------------------------------------------------------------------
-// Hand-scheduled kernels (4x8 outputs per lane).  Same arithmetic, but the instruction order
+// Hand-scheduled variant (8x8 outputs per lane).  Same arithmetic, but the instruction order
 // is pinned with inline asm because hipcc (ROCm 7.2) (a) places every v_pk_add directly behind
 // the v_pk_mul it depends on and (b) sinks the LDS reads of the next i-step below the current
-// step's math, so a wave stalls on both.  Here each i-step issues its 6 ds_read_b64 for the NEXT
-// step first, then 2 groups of {8 v_pk_mul, 8 v_pk_add} (dependent instructions 8 apart), then
+// step's math, so a wave stalls on both.  Here each i-step issues its 8 ds_read_b64 for the NEXT
+// step first, then 4 groups of {8 v_pk_mul, 8 v_pk_add} (dependent instructions 8 apart), then
 // one s_waitcnt: register set X feeds even steps, set Y odd steps (ping-pong, no copies).
 // ------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct Operands {  // one i-step's A (4 rows) and B (8 columns) values of this lane
-  f32x2 a0, a1, b0, b1, b2, b3;
+struct Operands {  // one i-step's A (8 rows) and B (8 columns) values of this lane
+  f32x2 a0, a1, a2, a3, b0, b1, b2, b3;
 };
 
 template <int BM, int BN>
 __device__ __forceinline__ void lds_fetch4(Operands &o, unsigned a_addr, unsigned b_addr, int ii) {
-  // 4-row lane tile: rows ty*4 .. ty*4+3
+  // 4-row lane tile: rows ty*4 .. ty*4+3 only (a2/a3 unused)
   asm volatile(
       "ds_read_b64 %0, %6 offset:%c8\n\t"
       "ds_read_b64 %1, %6 offset:%c9\n\t"
@@ -232,6 +240,34 @@ __device__ __forceinline__ void lds_fetch4(Operands &o, unsigned a_addr, unsigne
 __device__ __forceinline__ void lds_wait4(Operands &o) {
   asm volatile("s_waitcnt lgkmcnt(0)"
                : "+v"(o.a0), "+v"(o.a1), "+v"(o.b0), "+v"(o.b1), "+v"(o.b2), "+v"(o.b3)
+               :
+               : "memory");
+}
+
+template <int BM, int BN>
+__device__ __forceinline__ void lds_fetch(Operands &o, unsigned a_addr, unsigned b_addr, int ii) {
+  // asm loads: hipcc does not count them; every use is behind lds_wait() (cdna guide §5.7 iii).
+  // Outputs are early-clobber: the first ds_read must not land on the address registers the
+  // later ones still need.
+  asm volatile(
+      "ds_read_b64 %0, %8 offset:%c10\n\t"
+      "ds_read_b64 %1, %8 offset:%c11\n\t"
+      "ds_read_b64 %2, %8 offset:%c12\n\t"
+      "ds_read_b64 %3, %8 offset:%c13\n\t"
+      "ds_read_b64 %4, %9 offset:%c14\n\t"
+      "ds_read_b64 %5, %9 offset:%c15\n\t"
+      "ds_read_b64 %6, %9 offset:%c16\n\t"
+      "ds_read_b64 %7, %9 offset:%c17"
+      : "=&v"(o.a0), "=&v"(o.a1), "=&v"(o.a2), "=&v"(o.a3), "=&v"(o.b0), "=&v"(o.b1), "=&v"(o.b2), "=&v"(o.b3)
+      : "v"(a_addr), "v"(b_addr), "i"(ii * BM * 4), "i"(ii * BM * 4 + 8), "i"(ii * BM * 4 + BM * 2),
+        "i"(ii * BM * 4 + BM * 2 + 8), "i"(ii * BN * 4), "i"(ii * BN * 4 + 8), "i"(ii * BN * 4 + BN * 2),
+        "i"(ii * BN * 4 + BN * 2 + 8)
+      : "memory");
+}
+
+__device__ __forceinline__ void lds_wait(Operands &o) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(o.a0), "+v"(o.a1), "+v"(o.a2), "+v"(o.a3), "+v"(o.b0), "+v"(o.b1), "+v"(o.b2), "+v"(o.b3)
                :
                : "memory");
 }
@@ -367,17 +403,44 @@ __device__ __forceinline__ void step4(f32x2 (&acc)[4][4], const Operands &c, Ope
   }
 }
 
-// 64x128 (BM x BN) tile, 4x8 outputs per lane, register staging, two LDS slots per operand tile.
-template <int BM, int BN, int BK, int MINW>
-__global__ __launch_bounds__((BM / 4) * (BN / 8)) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
+#include "k1_step_scalar.inc"
+
+template <int TM>
+__device__ __forceinline__ void mac_step(f32x2 (&acc)[TM][4], const Operands &o) {
+  mac2rows(acc[0], acc[1], o.a0, o.b0, o.b1, o.b2, o.b3);
+  mac2rows(acc[2], acc[3], o.a1, o.b0, o.b1, o.b2, o.b3);
+  if constexpr (TM == 8) {
+    mac2rows(acc[4], acc[5], o.a2, o.b0, o.b1, o.b2, o.b3);
+    mac2rows(acc[6], acc[7], o.a3, o.b0, o.b1, o.b2, o.b3);
+  }
+}
+
+// ABL (tuning only, results are wrong when != 0): 1 = no staging/barrier inside the stage loop,
+// 2 = additionally no LDS operand reads inside the loop (pure VALU stream), 3 = staging but no
+// barrier, 4 = barrier but no staging.
+// SCALAR = v_mul_f32/v_add_f32 stream (TM == 4 only) instead of the packed v_pk_* one: on
+// gfx950 both forms have the same peak MAC rate, but the 2-cycle scalar ops reach it with fewer
+// waves per SIMD (profiles/r01_microbench_valu_mfma.txt: A vs B).
+// RING = LDS slots per operand tile: 2 = classic double buffer (stage s+1 is written at the end
+// of stage s, so its ds_writes must land before the barrier); 3 = stage s+2 is written at the end
+// of stage s into the slot nobody reads, the barrier publishes the writes of the PREVIOUS stage
+// and needs no LDS wait in front of it.
+// WLDS = the window (8 KiB) is copied to LDS once and read from there when a stage is written,
+// instead of 4 global loads per thread and stage.
+template <int BM, int BN, int BK, int MINW, int ABL = 0, int TM = 8, bool SCALAR = false, int RING = 2,
+          bool WLDS = false>
+__global__ __launch_bounds__((BM / TM) * (BN / 8)) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
 void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm, long long frame_begin, unsigned M,
                       float *__restrict__ coef) {
-  constexpr int TM = 4;
   using C = Cfg<BM, BN, BK, TM, 8, 2, MINW>;
-  __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+  static_assert(!SCALAR || TM == 4, "scalar stream is written for the 4x8 lane tile");
+  __shared__ __attribute__((aligned(16))) float As[RING][BK * BM];
+  __shared__ __attribute__((aligned(16))) float Bs[RING][BK * BN];
+  __shared__ float Ws[WLDS ? kFrameI : 1];
 
   const int tid = threadIdx.x;
+  if (WLDS)
+    for (int i = tid; i < kFrameI; i += C::kThreads) Ws[i] = tb.window[i];
   // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 says which blocks share an
   // L2).  Give XCD x the contiguous tile range [x*T/8, (x+1)*T/8) in (m_tile, n_tile) order: the
   // PCM rows of an m-tile are then fetched by ONE XCD instead of all eight, and the table rows of
@@ -428,20 +491,21 @@ void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm, long long frame_begin, unsig
 #pragma unroll
     for (int j = 0; j < C::kAPer; ++j) {
       a_raw[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, off0 + j * a_step, 0, 0));
-      a_win[j] = w_ptr[i0 + C::kAStride * j];
+      if (!WLDS) a_win[j] = w_ptr[i0 + C::kAStride * j];
     }
 #pragma unroll
     for (int j = 0; j < C::kBPer; ++j)
       b_stage[j] = *reinterpret_cast<const f32x4 *>(b_ptr + static_cast<size_t>(i0 + C::kBRowsPer * j) * kHopI);
   };
-  auto store_stage = [&](int buf) {
+  auto store_stage = [&](int buf, int i0) {
     // pin the first use of the staged registers behind the stage's math (volatile asm
     // statements keep their order): hipcc otherwise hoists the multiply, and with it the
     // vmcnt wait, into the middle of the stage
 #pragma unroll
     for (int j = 0; j < C::kAPer; ++j) {
-      float r = a_raw[j], w = a_win[j];
+      float r = a_raw[j], w = WLDS ? 0.0f : a_win[j];
       asm volatile("" : "+v"(r), "+v"(w));
+      if (WLDS) w = Ws[i0 + a_i + C::kAStride * j];
       As[buf][(a_i + C::kAStride * j) * BM + a_r] = mul_rn(r, w);  // block[i] = slice[i]*window[i], :480
     }
 #pragma unroll
@@ -453,13 +517,31 @@ void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm, long long frame_begin, unsig
   };
 
   f32x2 acc[TM][4];
+  float accs[4][8];
 #pragma unroll
   for (int r = 0; r < TM; ++r)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[r][c] = f32x2{0.0f, 0.0f};
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) accs[r][c] = 0.0f;
+  auto fetch = [&](Operands &o, unsigned a_addr, unsigned b_addr, int ii) {
+    if constexpr (TM == 8) lds_fetch<BM, BN>(o, a_addr, b_addr, ii);
+    else lds_fetch4<BM, BN>(o, a_addr, b_addr, ii);
+  };
+  auto wait = [&](Operands &o) {
+    if constexpr (TM == 8) lds_wait(o);
+    else lds_wait4(o);
+  };
 
+  if (WLDS) __syncthreads();
   load_stage(0);
-  store_stage(0);
+  store_stage(0, 0);
+  if (RING == 3) {
+    load_stage(BK);
+    store_stage(1, BK);
+  }
   __syncthreads();
 
   // LDS byte addresses of this lane's operand columns (low 32 bits of a generic LDS pointer)
@@ -469,28 +551,64 @@ void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm, long long frame_begin, unsig
   constexpr int kStages = kFrameI / BK;
 #pragma unroll 1
   for (int s = 0; s < kStages; ++s) {
-    const int buf = s & 1;
-    load_stage(((s + 1) & (kStages - 1)) * BK);
+    const int buf = RING == 3 ? s % 3 : (s & 1);
+    if (ABL == 0 || ABL == 3) load_stage(((s + RING - 1) & (kStages - 1)) * BK);
     const unsigned a_addr = a_lds0 + buf * (BK * BM * 4);
     const unsigned b_addr = b_lds0 + buf * (BK * BN * 4);
     Operands X, Y;
-    lds_fetch4<BM, BN>(X, a_addr, b_addr, 0);
-    lds_wait4(X);
-#pragma unroll
-    for (int ii = 0; ii < BK; ii += 2) {
-      step4<BM, BN, true>(acc, X, Y, a_addr, b_addr, ii + 1);
-      if (ii + 2 < BK) step4<BM, BN, true>(acc, Y, X, a_addr, b_addr, ii + 2);
-      else step4<BM, BN, false>(acc, Y, X, a_addr, b_addr, 0);
+    fetch(X, a_addr, b_addr, 0);
+    wait(X);
+    if (ABL == 2) {
+      fetch(Y, a_addr, b_addr, 1);
+      wait(Y);
     }
-    store_stage(buf ^ 1);
-    __syncthreads();
+    if constexpr (SCALAR && ABL != 2) {
+#pragma unroll
+      for (int ii = 0; ii < BK; ii += 2) {
+        step4s<BM, BN, true>(accs, X, Y, a_addr, b_addr, ii + 1);
+        if (ii + 2 < BK) step4s<BM, BN, true>(accs, Y, X, a_addr, b_addr, ii + 2);
+        else step4s<BM, BN, false>(accs, Y, X, a_addr, b_addr, 0);
+      }
+    } else if constexpr (TM == 4 && ABL != 2) {
+#pragma unroll
+      for (int ii = 0; ii < BK; ii += 2) {
+        step4<BM, BN, true>(acc, X, Y, a_addr, b_addr, ii + 1);
+        if (ii + 2 < BK) step4<BM, BN, true>(acc, Y, X, a_addr, b_addr, ii + 2);
+        else step4<BM, BN, false>(acc, Y, X, a_addr, b_addr, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ii = 0; ii < BK; ii += 2) {
+        if (ABL != 2) fetch(Y, a_addr, b_addr, ii + 1);
+        mac_step<TM>(acc, X);
+        if (ABL != 2) wait(Y);
+        if (ABL != 2 && ii + 2 < BK) fetch(X, a_addr, b_addr, ii + 2);
+        mac_step<TM>(acc, Y);
+        if (ABL != 2 && ii + 2 < BK) wait(X);
+      }
+    }
+    if (ABL == 3) store_stage(buf ^ 1, ((s + 1) & (kStages - 1)) * BK);
+    if (ABL == 4) __syncthreads();
+    if (ABL == 0) {
+      if (RING == 3) {
+        store_stage((s + 2) % 3, ((s + 2) & (kStages - 1)) * BK);
+        __builtin_amdgcn_s_barrier();  // publishes the writes made one stage ago; no LDS wait
+      } else {
+        store_stage(buf ^ 1, ((s + 1) & (kStages - 1)) * BK);
+        __syncthreads();
+      }
+    }
   }
 
 #pragma unroll
   for (int r = 0; r < TM; ++r) {
-    const unsigned row = m0 + ty * 4 + r;
+    const unsigned row = m0 + ((r < 4) ? (ty * 4 + r) : (BM / 2 + ty * 4 + (r - 4)));
     if (row >= M) continue;
     float *dst = coef + static_cast<size_t>(row) * kHopI + n0;
+    if constexpr (SCALAR) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[r][c] = f32x2{accs[r & 3][2 * c], accs[r & 3][2 * c + 1]};
+    }
     float4 o;
     o.x = mul_rn(acc[r][0].x, tb.norm); o.y = mul_rn(acc[r][0].y, tb.norm);
     o.z = mul_rn(acc[r][1].x, tb.norm); o.w = mul_rn(acc[r][1].y, tb.norm);
@@ -501,13 +619,15 @@ void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm, long long frame_begin, unsig
   }
 }
 
-template <int BM, int BN, int BK, int MINW>
+template <int BM, int BN, int BK, int MINW, int ABL = 0, int TM = 8, bool SCALAR = false, int RING = 2,
+          bool WLDS = false>
 inline hipError_t launch_sched(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M,
                                float *coef, hipStream_t s) {
-  using C = Cfg<BM, BN, BK, 4, 8, 2, MINW>;
+  using C = Cfg<BM, BN, BK, TM, 8, 2, MINW>;
   if (M == 0) return hipSuccess;
   const unsigned m_tiles = (M + BM - 1) / BM;
-  hipLaunchKernelGGL((k_mdct_fwd_sched<BM, BN, BK, MINW>), dim3(m_tiles * C::kNTiles), dim3(C::kThreads), 0, s, t, pcm,
+  hipLaunchKernelGGL((k_mdct_fwd_sched<BM, BN, BK, MINW, ABL, TM, SCALAR, RING, WLDS>), dim3(m_tiles * C::kNTiles),
+                     dim3(C::kThreads), 0, s, t, pcm,
                      static_cast<long long>(frame_begin), M, coef);
   return hipGetLastError();
 }
@@ -521,24 +641,27 @@ inline hipError_t launch_sched(const DeviceTables &t, const PcmView &pcm, uint64
 // `s_waitcnt vmcnt(1)` per stage waits for the PCM loads and the table DMA of the NEXT stage while
 // leaving the DMA of the stage after it in flight.  Same arithmetic, same order.
 // ------------------------------------------------------------------------------------------
-template <int MINW, int CH = 0>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
+template <int MINW, int ABL = 0, int BM = 128, int CH = 0>
+__global__ __launch_bounds__(4 * BM) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
 void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigned M, float *__restrict__ coef) {
   // CH = 0: one PCM dword per (row, i) and lane - any channel count.  CH = 1 / 2 / 4 / 8 (the
   // stream's channel count, which then divides the tile height): a stage's 16 samples x CH channels
   // of one frame are 64 * CH contiguous bytes, fetched by 4 * CH lanes with one dwordx4 each - 16x
   // fewer cache-line touches in the texture addresser than the per-row loader.
-  // 512 threads, 2 workgroups per CU (56 KiB LDS each).
-  constexpr int BM = 128, BN = 128, BK = 16, TM = 4, RING = 3;
-  constexpr int kThreads = 4 * BM;
+  // BM = 128: 512 threads, 2 workgroups per CU (56 KiB LDS each).  BM = 64: 256 threads, window
+  // values by scalar loads instead of LDS (36 KiB), 4 workgroups per CU - each SIMD then holds one
+  // wave of four DIFFERENT workgroups, whose barrier waits do not coincide.
+  constexpr int BN = 128, BK = 16, TM = 4, RING = 3;
+  constexpr int kThreads = 4 * BM, kWaves = kThreads / 64;
   constexpr int kAPer = 4, kAStride = 4;
+  constexpr bool kWinLds = BM == 128;
   constexpr bool kSeg = CH != 0;  // segment loader
-  static_assert(!kSeg || CH == 1 || CH == 2 || CH == 4 || CH == 8, "segment loader shapes");
+  static_assert(!kSeg || (BM == 128 && (CH == 1 || CH == 2 || CH == 4 || CH == 8)), "segment loader shapes");
   constexpr int kDma = (BK * BN * 4) / (kThreads * 16);  // table-DMA instructions per thread and stage
-  static_assert(kDma == 1, "one table-DMA instruction per thread and stage");
+  static_assert(BM == 128 || BM == 64, "tile heights with a hand-written schedule");
   __shared__ __attribute__((aligned(16))) float As[RING][BK * BM];
   __shared__ __attribute__((aligned(16))) float Bs[RING][BK * BN];
-  __shared__ __attribute__((aligned(16))) float Ws[kFrameI];
+  __shared__ __attribute__((aligned(16))) float Ws[kWinLds ? kFrameI : 4];
 
   const int tid = threadIdx.x;
   const unsigned g = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD-aware tile map
@@ -550,7 +673,8 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
 
-  for (int i = tid; i < kFrameI; i += kThreads) Ws[i] = tb.window[i];
+  if constexpr (kWinLds)
+    for (int i = tid; i < kFrameI; i += kThreads) Ws[i] = tb.window[i];
 
   const long long ch = pcm.ch;
   const long long f0 = frame_begin + m0 / pcm.ch;
@@ -567,6 +691,7 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
 
   const int a_r = tid % BM;
   const int a_i = tid / BM;  // 0..3: i = a_i + 4 j  (the same for every lane of a wave)
+  const int a_i_s = __builtin_amdgcn_readfirstlane(a_i);
   const unsigned a_row = m0 + a_r;
   unsigned a_off = 0x80000000u;
   if (a_row < M) {
@@ -590,12 +715,13 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
       a_off = static_cast<unsigned>((e_row - e_base + seg_o) * 4);
     }
   }
-  // table DMA: wave w copies rows 2 w, 2 w + 1 of the stage's 16 x 128 tile (1 KiB, lane-linear)
+  // table DMA: instruction d of wave w copies rows 2(d*kWaves + w), +1 of the stage's 16 x 128
+  // tile (1 KiB, lane-linear)
   const float *b_src = tb.cos_t + n0 + static_cast<size_t>(2 * wave + (lane >> 5)) * kHopI + (lane & 31) * 4;
 
   float a_raw[kAPer];
   f32x4 a_seg = {0.f, 0.f, 0.f, 0.f};
-  auto issue_a = [&](int i0) {  // asm: hipcc must not count these loads (see lds_fetch4)
+  auto issue_a = [&](int i0) {  // asm: hipcc must not count these loads (see lds_fetch)
     const unsigned o = a_off + static_cast<unsigned>(i0) * i_bytes;
     if constexpr (kSeg) {
       asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(a_seg) : "v"(o), "s"(a_rsrc) : "memory");
@@ -611,7 +737,35 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
         : "memory");
   };
   auto issue_b = [&](int i0, int slot) {
-    __builtin_amdgcn_global_load_lds(b_src + static_cast<size_t>(i0) * kHopI, &Bs[slot][2 * wave * BN], 16, 0, 0);
+#pragma unroll
+    for (int d = 0; d < kDma; ++d)
+      __builtin_amdgcn_global_load_lds(b_src + static_cast<size_t>(i0 + 2 * d * kWaves) * kHopI,
+                                       &Bs[slot][2 * (d * kWaves + wave) * BN], 16, 0, 0);
+  };
+  // window values of a stage: from LDS, or (BM = 64) four wave-uniform scalar loads.  hipcc would
+  // use vector loads here (it cannot prove the table unclobbered across the asm blocks) and then
+  // wait for vmcnt(0), DMA included, so the s_loads are written by hand; `pin_w` after an
+  // lgkmcnt(0) wait is what makes their results visible to the compiler-scheduled consumers.
+  float w_next[kAPer] = {0.f, 0.f, 0.f, 0.f}, w_far[kAPer] = {0.f, 0.f, 0.f, 0.f};
+  auto load_w = [&](int i0) {
+    if constexpr (!kWinLds) {
+      const float *wp = tb.window + i0 + a_i_s;
+      asm volatile(
+          "s_load_dword %0, %4, 0x0\n\t"
+          "s_load_dword %1, %4, 0x10\n\t"
+          "s_load_dword %2, %4, 0x20\n\t"
+          "s_load_dword %3, %4, 0x30"
+          : "=&s"(w_far[0]), "=&s"(w_far[1]), "=&s"(w_far[2]), "=&s"(w_far[3])
+          : "s"(wp)
+          : "memory");
+    }
+  };
+  auto pin_w = [&]() {  // call only behind an lgkmcnt(0) wait
+    if constexpr (!kWinLds) {
+      asm volatile("" : "+s"(w_far[0]), "+s"(w_far[1]), "+s"(w_far[2]), "+s"(w_far[3]));
+#pragma unroll
+      for (int j = 0; j < kAPer; ++j) w_next[j] = w_far[j];
+    }
   };
   auto store_a = [&](int i0, int slot) {
     if constexpr (kSeg) {
@@ -626,14 +780,17 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
 #pragma unroll
     for (int j = 0; j < kAPer; ++j) {
       const int ii = a_i + kAStride * j;
-      As[slot][ii * BM + a_r] = mul_rn(a_raw[j], Ws[i0 + ii]);  // block[i] = slice[i]*window[i], :480
+      const float wv = kWinLds ? Ws[i0 + ii] : w_next[j];
+      As[slot][ii * BM + a_r] = mul_rn(a_raw[j], wv);  // block[i] = slice[i]*window[i], :480
     }
   };
   auto wait_all_but_newest_dma = [&]() {
     if constexpr (kSeg)
       asm volatile("s_waitcnt vmcnt(1)" : "+v"(a_seg)::"memory");
-    else
+    else if constexpr (kDma == 1)
       asm volatile("s_waitcnt vmcnt(1)" : "+v"(a_raw[0]), "+v"(a_raw[1]), "+v"(a_raw[2]), "+v"(a_raw[3])::"memory");
+    else
+      asm volatile("s_waitcnt vmcnt(2)" : "+v"(a_raw[0]), "+v"(a_raw[1]), "+v"(a_raw[2]), "+v"(a_raw[3])::"memory");
   };
 
   f32x2 acc[TM][4];
@@ -647,12 +804,16 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
   __syncthreads();  // Ws
   issue_a(0);
   issue_b(0, 0);
+  load_w(0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
                : "+v"(a_raw[0]), "+v"(a_raw[1]), "+v"(a_raw[2]), "+v"(a_raw[3]), "+v"(a_seg)::"memory");
+  pin_w();
   store_a(0, 0);
   issue_a(BK);
   issue_b(BK, 1);
+  load_w(BK);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  pin_w();
   __syncthreads();
 
   const unsigned a_lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(&As[0][ty * 4]));
@@ -662,25 +823,29 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
   for (int s = 0; s < kStages; ++s) {
     const int slot = s % 3;
     // in flight on entry: PCM loads of stage s+1 (regs) and table DMA of stage s+1 (slot (s+1)%3)
-    issue_b(((s + 2) & (kStages - 1)) * BK, (s + 2) % 3);  // slot of stage s-1: free since the barrier
+    if (ABL == 0) issue_b(((s + 2) & (kStages - 1)) * BK, (s + 2) % 3);  // slot of stage s-1: free since the barrier
     const unsigned a_addr = a_lds0 + slot * (BK * BM * 4);
     const unsigned b_addr = b_lds0 + slot * (BK * BN * 4);
     Operands X, Y;
+    if (ABL == 0 && s > 0) load_w(((s + 1) & (kStages - 1)) * BK);  // s == 0: loaded by the prologue
     lds_fetch4<BM, BN>(X, a_addr, b_addr, 0);
-    lds_wait4(X);
+    lds_wait4(X);  // lgkmcnt(0): the scalar loads above are back as well
+    if (ABL == 0 && s > 0) pin_w();
 #pragma unroll
     for (int ii = 0; ii < BK; ii += 2) {
       step4<BM, BN, true>(acc, X, Y, a_addr, b_addr, ii + 1);
       if (ii + 2 < BK) step4<BM, BN, true>(acc, Y, X, a_addr, b_addr, ii + 2);
       else step4<BM, BN, false>(acc, Y, X, a_addr, b_addr, 0);
     }
-    // everything but the youngest vector-memory op (the DMA of stage s+2) has landed: the PCM
-    // registers of stage s+1 and, older still, the table DMA of stage s+1
-    wait_all_but_newest_dma();
-    store_a(((s + 1) & (kStages - 1)) * BK, (s + 1) % 3);
-    issue_a(((s + 2) & (kStages - 1)) * BK);
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's ds_writes of stage s+1 have landed
-    __builtin_amdgcn_s_barrier();
+    if (ABL == 0) {
+      // everything but the youngest vector-memory ops (the DMA of stage s+2) has landed: the PCM
+      // registers of stage s+1 and, older still, the table DMA of stage s+1
+      wait_all_but_newest_dma();
+      store_a(((s + 1) & (kStages - 1)) * BK, (s + 1) % 3);
+      issue_a(((s + 2) & (kStages - 1)) * BK);
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's ds_writes of stage s+1 have landed
+      __builtin_amdgcn_s_barrier();
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the wrap-around prefetches
 
@@ -699,13 +864,140 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
   }
 }
 
-template <int MINW, int CH = 0>
+template <int MINW, int ABL = 0, int BM = 128, int CH = 0>
 inline hipError_t launch_dma(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M,
                              float *coef, hipStream_t s) {
   if (M == 0) return hipSuccess;
   if (CH != 0 && pcm.ch != static_cast<uint32_t>(CH)) return hipErrorInvalidValue;
+  const unsigned m_tiles = (M + BM - 1) / BM;
+  hipLaunchKernelGGL((k_mdct_fwd_dma<MINW, ABL, BM, CH>), dim3(m_tiles * 8), dim3(4 * BM), 0, s, t, pcm,
+                     static_cast<long long>(frame_begin), M, coef);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Matrix-pipe multiplier variant (tuning harness only).  `v_mfma_f32_32x32x1_2b_f32` with C = 0
+// returns exactly the bits of v_mul_f32 (tools/mfma_probe.hip), so the products of one i-step of
+// a 32-row x 64-column wave tile can come from ONE matrix instruction (two 32x32 outer products:
+// the A operand is one x value per row, the B operand one table value per column) and only the
+// separately rounded accumulation stays on the vector ALU: acc += P as v_pk_add_f32.  Same
+// arithmetic, same order.  The f32 matrix pipe does not co-issue with the VALU, so
+// this wins no issue slots; what it removes is operand traffic: 3 ds_read_b32 per 4096 MACs
+// instead of 12 ds_read_b64, and the multiply's VGPR operand reads.
+//   tile 128 x 128, 256 threads: wave w owns rows 64 (w / 2) .. +64 and columns 64 (w % 2) .. +64
+// ------------------------------------------------------------------------------------------
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+
+template <int BK, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_mdct_fwd_mx(DeviceTables tb, PcmView pcm, long long frame_begin,
+                                                          unsigned M, float *__restrict__ coef) {
+  constexpr int BM = 128, BN = 128, kThreads = 256;
+  constexpr int kAPer = BM * BK / kThreads, kAStride = kThreads / BM;
+  constexpr int kBPer = BK * BN / 4 / kThreads, kBRowsPer = kThreads / (BN / 4);
+  __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+
+  const int tid = threadIdx.x;
+  const unsigned g = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD-aware tile map
+  const int n_tile = g % 8, m_tile = g / 8;
+  const int m0 = m_tile * BM, n0 = n_tile * BN;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int r0 = (wave >> 1) * 64, c0 = (wave & 1) * 64;
+
+  const long long ch = pcm.ch;
+  const long long f0 = frame_begin + m0 / pcm.ch;
+  const long long e_first = (f0 * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * ch;
+  long long e_end = static_cast<long long>(pcm.t_count) * ch;
+  const long long n_rel = static_cast<long long>(pcm.n_samples) - static_cast<long long>(pcm.t0) * ch;
+  if (e_end > n_rel) e_end = n_rel;
+  const long long e_base = e_first < 0 ? 0 : e_first;
+  long long e_cnt = e_end - e_base;
+  if (e_cnt < 0) e_cnt = 0;
+  if (e_cnt > (1ll << 28)) e_cnt = 1ll << 28;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(pcm.p + e_base), 0, static_cast<int>(e_cnt * 4), 0x00020000);
+  const int a_r = tid % BM, a_i = tid / BM;
+  const unsigned a_row = m0 + a_r;
+  unsigned a_off = 0x80000000u;
+  if (a_row < M) {
+    const long long f = frame_begin + a_row / pcm.ch;
+    const long long c = a_row % pcm.ch;
+    const long long e_row = (f * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * ch + c;
+    a_off = static_cast<unsigned>((e_row - e_base + a_i * ch) * 4);
+  }
+  const unsigned a_step = static_cast<unsigned>(kAStride * ch * 4);
+  const float *w_ptr = tb.window + a_i;
+  const int b_r = tid / (BN / 4), b_c4 = tid % (BN / 4);
+  const float *b_ptr = tb.cos_t + n0 + static_cast<size_t>(b_r) * kHopI + b_c4 * 4;
+
+  float a_stage[kAPer];
+  float4 b_stage[kBPer];
+  auto load_stage = [&](int i0) {
+    const unsigned off0 = a_off + static_cast<unsigned>(i0) * static_cast<unsigned>(ch * 4);
+#pragma unroll
+    for (int j = 0; j < kAPer; ++j) {
+      const float x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, off0 + j * a_step, 0, 0));
+      a_stage[j] = mul_rn(x, w_ptr[i0 + kAStride * j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kBPer; ++j)
+      b_stage[j] = *reinterpret_cast<const float4 *>(b_ptr + static_cast<size_t>(i0 + kBRowsPer * j) * kHopI);
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < kAPer; ++j) As[buf][(a_i + kAStride * j) * BM + a_r] = a_stage[j];
+#pragma unroll
+    for (int j = 0; j < kBPer; ++j)
+      *reinterpret_cast<float4 *>(&Bs[buf][(b_r + kBRowsPer * j) * BN + b_c4 * 4]) = b_stage[j];
+  };
+
+  f32x32 acc0, acc1, zero;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) acc0[j] = 0.0f, acc1[j] = 0.0f, zero[j] = 0.0f;
+
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+
+  constexpr int kStages = kFrameI / BK;
+#pragma unroll 1
+  for (int s = 0; s < kStages; ++s) {
+    const int buf = s & 1;
+    load_stage(((s + 1) & (kStages - 1)) * BK);
+    const float *Ab = As[buf] + r0 + (lane & 31);
+    const float *Bb = Bs[buf] + c0 + lane;
+#pragma unroll
+    for (int ii = 0; ii < BK; ++ii) {
+      const float a0 = Ab[ii * BM], a1 = Ab[ii * BM + 32], b = Bb[ii * BN];
+      const f32x32 p0 = __builtin_amdgcn_mfma_f32_32x32x1f32(a0, b, zero, 0, 0, 0);  // fl(a*b), one per output
+      acc0 = acc0 + p0;                                                             // separately rounded add
+      const f32x32 p1 = __builtin_amdgcn_mfma_f32_32x32x1f32(a1, b, zero, 0, 0, 0);
+      acc1 = acc1 + p1;
+    }
+    store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // vgpr j of block j / 16: column = lane % 32 + 32 (j / 16), row = 8 ((j % 16) / 4) + 4 (lane / 32) + j % 4
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const f32x32 &acc = half ? acc1 : acc0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int jj = j % 16;
+      const unsigned row = m0 + r0 + half * 32 + 8 * (jj / 4) + 4 * (lane >> 5) + (jj % 4);
+      if (row >= M) continue;
+      coef[static_cast<size_t>(row) * kHopI + n0 + c0 + (lane & 31) + 32 * (j / 16)] = mul_rn(acc[j], tb.norm);
+    }
+  }
+}
+
+template <int BK, int MINW>
+inline hipError_t launch_mx(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M, float *coef,
+                            hipStream_t s) {
+  if (M == 0) return hipSuccess;
   const unsigned m_tiles = (M + 127) / 128;
-  hipLaunchKernelGGL((k_mdct_fwd_dma<MINW, CH>), dim3(m_tiles * 8), dim3(512), 0, s, t, pcm,
+  hipLaunchKernelGGL((k_mdct_fwd_mx<BK, MINW>), dim3(m_tiles * 8), dim3(256), 0, s, t, pcm,
                      static_cast<long long>(frame_begin), M, coef);
   return hipGetLastError();
 }
@@ -721,5 +1013,5 @@ inline hipError_t launch(const DeviceTables &t, const PcmView &pcm, uint64_t fra
   return hipGetLastError();
 }
 
-}  // namespace k1
+}  // namespace k1x
 }  // namespace glc

@@ -1,7 +1,9 @@
 """Soak of the decode kernels: random sparse streams (random list lengths 0..400, a random share of
-common indices, random raw frames) are decoded with the grouped IMDCT (8 rows per workgroup, LDS
-union map built with atomics) and with the one-row kernel (GLC_D1_GROUP=0); the outputs must be
-bit-identical.  Usage: python tools/soak_decode.py [rounds]"""
+common indices, random raw frames, 1..3 channels) are decoded four ways - the shipped k_imdct_chan<8>
+(path chosen per group), the same kernel forced onto its sparse and onto its dense path, and the
+one-row kernel (include/glc_debug.h) - and all outputs must be bit-identical.
+Usage: python tools/soak_decode.py [rounds]"""
+import ctypes as C
 import os
 import sys
 import time
@@ -14,15 +16,18 @@ sys.path.insert(0, ROOT)
 import glc_amd  # noqa: E402
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-ch, nf = 2, 2048
-M = nf * ch
-rec = glc_amd.lib.glc_record_bytes(ch)
-hdr = rec - 4096 * ch
-dec = glc_amd.Decoder(ch, 48000)
+glc_amd.lib.glc_debug_set_imdct_variant.restype = C.c_int
+glc_amd.lib.glc_debug_set_imdct_variant.argtypes = [C.c_void_p, C.c_int]
+dec = glc_amd.Decoder(2, 48000)
 bad = 0
 t0 = time.time()
 for r in range(rounds):
     rng = np.random.default_rng(1000 + r)
+    ch = int(rng.choice([1, 2, 2, 2, 3]))
+    nf = int(rng.choice([2048, 2048, 1027, 333]))
+    M = nf * ch
+    rec = glc_amd.lib.glc_record_bytes(ch)
+    hdr = rec - 4096 * ch
     nnz = rng.integers(0, 401, M)
     nnz[rng.random(M) < 0.05] = 0
     order = np.argsort(rng.random((M, 1024)), axis=1)                 # a random permutation of the bins per row
@@ -46,17 +51,18 @@ for r in range(rounds):
     buf[:, 0:4].view(np.uint32)[:, 0] = raw_frame
     ea = glc_amd.EncodedAudio.from_records(48000, nf * 1024 * ch, ch, buf.reshape(-1))
     outs = []
-    for g in ("8", "0"):
-        os.environ["GLC_D1_GROUP"] = g
+    for variant in (0, 1, 2, 3):
+        assert glc_amd.lib.glc_debug_set_imdct_variant(dec._h, variant) == 0
         d = torch.full(((nf + 1) * 1024 * ch,), float("nan"), dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()
         dec.decode_device(ea, d.data_ptr(), d.numel())
         dec.synchronize()
         outs.append(d.cpu().numpy().view(np.uint32))
-    if not np.array_equal(outs[0], outs[1]):
+    if not all(np.array_equal(outs[0], o) for o in outs[1:]):
         bad += 1
-        print(f"round {r}: outputs differ in {int((outs[0] != outs[1]).sum())} samples", flush=True)
+        print(f"round {r} (ch {ch}, {nf} frames): outputs differ in "
+              f"{[int((outs[0] != o).sum()) for o in outs[1:]]} samples (one-row / sparse / dense)", flush=True)
     if r % 10 == 9 or r == rounds - 1:
         print(f"decode soak round {r + 1}: {bad} differing streams so far ({time.time() - t0:.0f} s)", flush=True)
-os.environ.pop("GLC_D1_GROUP", None)
+glc_amd.lib.glc_debug_set_imdct_variant(dec._h, 0)
 sys.exit(1 if bad else 0)
