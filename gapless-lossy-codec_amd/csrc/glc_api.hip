@@ -88,6 +88,8 @@ struct glc_ctx {
   DevBuf records;    // staging for host-boundary encode
   DevBuf blocks;     // decode: windowed IMDCT blocks [(chunk+1)][ch][2048]
   DevBuf dec_meta;   // decode: pairs / offsets / scales / raw pool
+  DevBuf dec_plan;   // decode: union records of the (group, channel) units of one D1 launch
+  uint32_t dec_plan_groups = 0;
   DevBuf pack_meta;  // compaction scratch: loc, blk, blk_raw, totals
   DevBuf pack_blob;  // compaction: the compact blob of glc_encode / glc_frames_from_device_records
   HostBuf host_stage;  // pinned: the blob on its way to the host
@@ -111,6 +113,8 @@ namespace {
 
 constexpr uint64_t kEncodeChunkFrames = 4096;  // rows per K1/K2/K3 round: coef stays MALL-sized
 constexpr uint64_t kDecodeChunkFrames = 4096;
+
+constexpr uint32_t kPlanGroups = 2048;  // (group, channel) units per D1 batch: 135 MB of workspace
 
 int fail(glc_ctx *ctx, int code, const std::string &msg) {
   if (ctx) ctx->err = msg;
@@ -265,6 +269,7 @@ void glc_ctx_destroy(glc_ctx *ctx) {
   ctx->records.release();
   ctx->blocks.release();
   ctx->dec_meta.release();
+  ctx->dec_plan.release();
   ctx->pack_meta.release();
   ctx->pack_blob.release();
   ctx->host_stage.release();
@@ -571,6 +576,11 @@ int decode_prepare_impl(glc_ctx *ctx, const glc_frames *in) {
   const uint64_t nf = in->n_frames;
   const uint64_t M = nf * ch;
   if (M > 0xFFFFFFFFull) return fail(ctx, GLC_EINVAL, "glc_decode: stream too long");
+  if (ctx->d1_variant != 1) {
+    DeviceGuard guard_plan(ctx->device);
+    ctx->dec_plan_groups = std::max<uint32_t>(kPlanGroups, ch);  // at least one frame group of all channels
+    GLC_HIP(ctx, ctx->dec_plan.reserve(glc::imdct_plan_bytes(ctx->dec_plan_groups)));
+  }
   // The sparse rows of this stream are still on the device from an earlier call (a glc_frames is
   // immutable and its uid is unique in the process): nothing to prepare or upload.
   if (ctx->dec_uid != 0 && ctx->dec_uid == in->uid) {
@@ -698,7 +708,7 @@ int round_launch(glc_ctx *ctx, uint64_t round_frames, bool flush_at_full, float 
   if (n)
     GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, static_cast<uint32_t>(f0 * ch),
                                         static_cast<uint32_t>(n * ch), ch, blocks + slot, ctx->stream,
-                                        ctx->d1_variant));
+                                        ctx->d1_variant, ctx->dec_plan.p, ctx->dec_plan.p ? ctx->dec_plan_groups : 0));
   GLC_HIP(ctx, glc::launch_overlap_add(blocks, static_cast<int64_t>(f0) - 1, nf, ch, f0, f0 + n + (last ? 1 : 0), dout,
                                        ctx->stream));
   if (!last)
@@ -738,7 +748,7 @@ int decode_hops_prepared(glc_ctx *ctx, uint64_t hop_begin, uint64_t hop_end, flo
     GLC_HIP(ctx, hipMemsetAsync(blocks, 0, slot * sizeof(float), ctx->stream));  // overlap = 0.0, :601
   else
     GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, static_cast<uint32_t>((hop_begin - 1) * ch), ch, ch,
-                                        blocks, ctx->stream, ctx->d1_variant));
+                                        blocks, ctx->stream, ctx->d1_variant, ctx->dec_plan.p, ctx->dec_plan.p ? ctx->dec_plan_groups : 0));
   uint64_t f0 = hop_begin;
   do {
     const uint64_t nchunk = f0 < f_end ? std::min(chunk, f_end - f0) : 0;
@@ -746,7 +756,7 @@ int decode_hops_prepared(glc_ctx *ctx, uint64_t hop_begin, uint64_t hop_end, flo
     if (nchunk)
       GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, static_cast<uint32_t>(f0 * ch),
                                           static_cast<uint32_t>(nchunk * ch), ch, blocks + slot, ctx->stream,
-                                          ctx->d1_variant));
+                                          ctx->d1_variant, ctx->dec_plan.p, ctx->dec_plan.p ? ctx->dec_plan_groups : 0));
     GLC_HIP(ctx, glc::launch_overlap_add(blocks, static_cast<int64_t>(f0) - 1, nf, ch, f0, f0 + nchunk + (tail ? 1 : 0),
                                          d_out + (f0 - hop_begin) * glc::kHop * ch, ctx->stream));
     f0 += nchunk + (tail ? 1 : 0);
@@ -862,12 +872,12 @@ int glc_imdct_device(glc_ctx *ctx, const glc_frames *in, uint64_t frame_begin, u
   const uint32_t ch = ctx->dec_ch;
   GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, static_cast<uint32_t>(frame_begin * ch),
                                       static_cast<uint32_t>((frame_end - frame_begin) * ch), ch, d_blocks, ctx->stream,
-                                      ctx->d1_variant));
+                                      ctx->d1_variant, ctx->dec_plan.p, ctx->dec_plan.p ? ctx->dec_plan_groups : 0));
   return GLC_OK;
 }
 
 int glc_debug_set_imdct_variant(glc_ctx *ctx, int variant) {
-  if (!ctx || variant < 0 || variant > 3) return fail(ctx, GLC_EINVAL, "glc_debug_set_imdct_variant: variant must be 0..3");
+  if (!ctx || variant < 0 || variant > 2) return fail(ctx, GLC_EINVAL, "glc_debug_set_imdct_variant: variant must be 0..2");
   ctx->d1_variant = variant;
   return GLC_OK;
 }

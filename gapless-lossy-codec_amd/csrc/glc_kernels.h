@@ -63,10 +63,14 @@ struct DecodeRows {
   const uint64_t *row_raw_len;
   const int16_t *raw_pool;
 };
-// variant: 0 = shipped (k_imdct_chan<8>, path chosen per group); 1 = one row per workgroup (the
-// cross-check kernel); 2 / 3 = k_imdct_chan<8> forced onto its sparse / dense path.
+// variant (include/glc_debug.h): 0 = shipped (k_imdct_plan + k_imdct_apply, absent row pairs skipped
+// by scalar branches); 1 = one row per workgroup (the cross-check kernel); 2 = plan + apply without
+// the skip.  Variants 0 and 2 need a workspace `plan` of imdct_plan_bytes(plan_groups) bytes,
+// plan_groups >= ch (launches with more (frame group, channel) units go through it in batches).
+uint64_t imdct_plan_bytes(uint32_t groups);
 hipError_t launch_imdct_rows(const DeviceTables &t, const DecodeRows &rows, uint32_t row_begin,
-                             uint32_t M, uint32_t ch, float *blocks, hipStream_t s, int variant = 0);
+                             uint32_t M, uint32_t ch, float *blocks, hipStream_t s, int variant = 0,
+                             void *plan = nullptr, uint32_t plan_groups = 0);
 // D2: overlap-add + interleave of hops [hop_begin, hop_end) into out (hop h = second half of
 // frame h-1 + first half of frame h; hop n_frames is the bare overlap tail).  `blocks` holds
 // frames blk_frame0, blk_frame0+1, ... (blk_frame0 may be -1: a zero "frame before the first").

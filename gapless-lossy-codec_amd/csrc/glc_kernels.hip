@@ -330,64 +330,52 @@ __global__ __launch_bounds__(256) void k_imdct_rows(DeviceTables tb, DecodeRows 
 }
 
 // ------------------------------------------------------------------------------------------
-// D1, SHIPPED: one workgroup decodes G consecutive frames of ONE channel (rows f*ch + c,
-// f = f0 .. f0+G-1) over the UNION of their coefficient indices, so that a table row is read from
-// L2 once for the group.  Consecutive frames of one channel are the rows that share indices:
+// D1, SHIPPED: plan + apply.  A unit of work is 8 consecutive frames of ONE channel (rows f*ch + c,
+// f = f0 .. f0+7) decoded over the UNION of their coefficient indices, so that a table row is read
+// from L2 once for the group.  Consecutive frames of one channel are the rows that share indices:
 // tonal material keeps its partials from frame to frame, while two channels may carry different
-// instruments.  Per row the arithmetic is the reference's: its non-zeros applied in ascending k.
-//
-//   dense path  (the union is at most 3x the mean list): EVERY row of the group takes every union
-//               entry, branch-free - a row that lacks the index multiplies by its +0.0 and adds the
-//               signed zero, which is the identity on a running sum that is never -0.0 (the same
-//               identity the sparse skip rests on).  The entry step is hand-scheduled like K1's:
-//               4 x {8 v_pk_mul_f32, 8 v_pk_add_f32} with dependent instructions 8 apart, the table
-//               row of the next entry already in flight (global_load_dwordx4 issued one whole
-//               entry ahead, retired by a counted vmcnt), coefficients and union indices by
-//               broadcast ds_reads under counted lgkmcnt waits (tools/d1_tune.hip has the
-//               measurements behind these choices).
-//   sparse path (little sharing, e.g. transients): per (entry, row) wave-uniform skip, compiler-
-//               scheduled - the round-1 kernel's loop.
-//   LDS: dense coefficients [k][G] (zero = absent), a 1024-bit union map, the ascending union list.
-// `mode`: 0 = choose per group; 2 / 3 force the sparse / dense path (soak tools, glc_debug.h).
+// instruments.  Per row the arithmetic is the reference's: its stored non-zeros applied in ascending
+// k; a row that lacks an index of the union multiplies the table row by its +0.0 and adds the signed
+// zero, which is the identity on a running sum that is never -0.0 (the same identity the sparse skip
+// of the one-row kernel rests on).
+//   k_imdct_plan   one workgroup per (group, channel): raw rows are written out directly; the other
+//                  rows are dequantised into LDS, the ascending union of their indices is built and
+//                  written to global memory as 64-byte records {8 coefficients (+0.0 = absent), byte
+//                  offset of the table row of entry j+2}, with a header {n_u, live rows, offsets of
+//                  entries 0 and 1}.
+//   k_imdct_apply  no LDS, no barrier: each wave owns 8 rows x 512 outputs.  The record of the next
+//                  entry arrives by scalar loads (s_load_dwordx8 + s_load_dword) a whole entry ahead;
+//                  the coefficient pairs feed v_pk_mul_f32 straight from SGPRs (lane-broadcast by
+//                  op_sel); the table row of the entry after next is in flight by
+//                  global_load_dwordx4 from an SGPR base.  The vector ALU executes the 64 packed
+//                  multiplies / adds of an entry and nothing else; a row pair whose two coefficients
+//                  are both absent is skipped by a scalar branch (SKIP), so groups that share few
+//                  indices degrade gracefully instead of needing a second code path.
 // ------------------------------------------------------------------------------------------
 typedef float d1x2 __attribute__((ext_vector_type(2)));
 typedef float d1x4 __attribute__((ext_vector_type(4)));
+typedef unsigned d1u8 __attribute__((ext_vector_type(8)));
+typedef unsigned d1u2 __attribute__((ext_vector_type(2)));
+constexpr unsigned kPlanRecDwords = 16;       // 64-byte records
+constexpr unsigned kPlanHdrDwords = 8;        // {n_u, live rows, table offsets of the first <= 4 entries, pad}
+constexpr unsigned kPlanRecCap = kHopI + 8;   // per group: the union holds <= 1024 entries; the apply loop reads a few past
 
-// table row k, this lane's 2 x 4 outputs: T[k][4 tid ..] and T[k][1024 + 4 tid ..]; `base` is
-// biased by +2048 B so that both halves are within the 13-bit signed instruction offset
-__device__ __forceinline__ void d1_issue_table(d1x4 &lo, d1x4 &hi, unsigned voff, const float *base) {
-  asm volatile(
-      "global_load_dwordx4 %0, %2, %3 offset:-2048\n\t"
-      "global_load_dwordx4 %1, %2, %3 offset:2048"
-      : "=&v"(lo), "=&v"(hi)
-      : "v"(voff), "s"(base)
-      : "memory");
-}
-template <int G>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void k_imdct_chan(DeviceTables tb, DecodeRows rows, unsigned row_begin, unsigned n_frames, unsigned ch, int mode,
-                  float *__restrict__ blocks) {
-  static_assert(G == 8, "the entry step is written for 8 rows (4 coefficient pairs)");
+__global__ __launch_bounds__(256) void k_imdct_plan(DecodeRows rows, unsigned row_begin, unsigned n_frames, unsigned ch,
+                                                     unsigned group_begin, unsigned ahead, unsigned *__restrict__ plan_hdr,
+                                                     unsigned *__restrict__ plan_rec, float *__restrict__ blocks) {
+  constexpr int G = 8;
   __shared__ __attribute__((aligned(16))) float s_c[kHopI * G];
   __shared__ unsigned s_mask[kHopI / 32];
   __shared__ unsigned short s_u[kHopI + 8];
   __shared__ unsigned s_wsum[4];
   const int tid = threadIdx.x;
-  // block -> (frame group, channel): workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8),
-  // and channels can differ in how many coefficients they keep, so every XCD takes frame groups of
-  // ALL channels: block 8 q + x handles channel q % ch of frame group (q / ch) * 8 + x.  The grid is
-  // padded to a multiple of 8 groups; surplus blocks leave at once.  (Speed only, never results.)
-  const unsigned q_ = blockIdx.x >> 3;
-  const unsigned c = q_ % ch;
-  const unsigned fr0 = ((q_ / ch) * 8u + (blockIdx.x & 7u)) * G;  // first frame of the group, relative to the launch
-  if (fr0 >= n_frames) return;
-
+  // blockIdx = (frame group - fg_begin) * ch + channel: the batch covers whole frame groups
+  const unsigned c = blockIdx.x % ch;
+  const unsigned fr0 = (group_begin + blockIdx.x / ch) * G;
   for (int i = tid; i < kHopI * G; i += 256) s_c[i] = 0.0f;
   if (tid < kHopI / 32) s_mask[tid] = 0u;
   __syncthreads();
-
-  unsigned live = 0;   // rows of the group that take the transform path (uniform)
-  unsigned total = 0;  // their list lengths (uniform)
+  unsigned live = 0;
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     const unsigned fr = fr0 + g;
@@ -411,7 +399,6 @@ void k_imdct_chan(DeviceTables tb, DecodeRows rows, unsigned row_begin, unsigned
     live |= 1u << g;
     const unsigned long long p0 = rows.row_begin[m];
     const unsigned n = min(rows.row_cnt[m], static_cast<unsigned>(kHopI));  // canonical lists hold <= 1024
-    total += n;
     const float scale = fmaxf(rows.row_scale[m], 1e-12f);                  // :653
     for (unsigned j = tid; j < n; j += 256) {
       const unsigned pr = rows.pairs[p0 + j];
@@ -424,7 +411,6 @@ void k_imdct_chan(DeviceTables tb, DecodeRows rows, unsigned row_begin, unsigned
     }
   }
   __syncthreads();
-
   // ascending union list: thread t owns bins 4t..4t+3; exclusive scan of the per-thread counts
   const unsigned nib = (s_mask[tid >> 3] >> ((tid & 7) * 4)) & 0xFu;
   const unsigned cnt = __popc(nib);
@@ -451,119 +437,169 @@ void k_imdct_chan(DeviceTables tb, DecodeRows rows, unsigned row_begin, unsigned
       if (nib & (1u << b)) s_u[pos++] = static_cast<unsigned short>(tid * 4 + b);
   }
   __syncthreads();
-  if (!live) return;
-  // the dense loop prefetches up to 4 entries past the end: give it valid indices to fetch
-  if (tid < 8) s_u[n_u + tid] = n_u ? s_u[n_u - 1] : static_cast<unsigned short>(0);
+  if (tid < 8) s_u[n_u + tid] = n_u ? s_u[n_u - 1] : static_cast<unsigned short>(0);  // run-ahead reads stay valid
   __syncthreads();
+  unsigned *rec = plan_rec + static_cast<size_t>(blockIdx.x) * kPlanRecCap * kPlanRecDwords;
+  for (unsigned j = tid; j < n_u; j += 256) {
+    const unsigned k = s_u[j];
+    d1x4 *dst = reinterpret_cast<d1x4 *>(rec + static_cast<size_t>(j) * kPlanRecDwords);
+    dst[0] = *reinterpret_cast<const d1x4 *>(&s_c[k * G]);
+    dst[1] = *reinterpret_cast<const d1x4 *>(&s_c[k * G + 4]);
+    rec[static_cast<size_t>(j) * kPlanRecDwords + 8] = static_cast<unsigned>(s_u[j + ahead]) << 13;  // table row bytes = 8192
+  }
+  if (tid < 8) {
+    unsigned *h = plan_hdr + static_cast<size_t>(blockIdx.x) * kPlanHdrDwords;
+    h[tid] = tid == 0 ? n_u : tid == 1 ? live : tid < 2 + ahead ? static_cast<unsigned>(s_u[tid - 2]) << 13 : 0u;
+  }
+}
+
+// rows (r, r+1) x 8 columns, coefficient pair in SGPRs: the same instruction block as k1::mac2rows
+__device__ __forceinline__ void d1_mac2rows_s(d1x2 (&c0)[4], d1x2 (&c1)[4], d1u2 a, d1x2 b0, d1x2 b1, d1x2 b2, d1x2 b3) {
+  d1x2 t0, t1, t2, t3, t4, t5, t6, t7;
+  asm volatile(
+      "v_pk_mul_f32 %8, %16, %17 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %9, %16, %18 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %10, %16, %19 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %11, %16, %20 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %12, %16, %17 op_sel:[1,0]\n\t"
+      "v_pk_mul_f32 %13, %16, %18 op_sel:[1,0]\n\t"
+      "v_pk_mul_f32 %14, %16, %19 op_sel:[1,0]\n\t"
+      "v_pk_mul_f32 %15, %16, %20 op_sel:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, %8\n\t"
+      "v_pk_add_f32 %1, %1, %9\n\t"
+      "v_pk_add_f32 %2, %2, %10\n\t"
+      "v_pk_add_f32 %3, %3, %11\n\t"
+      "v_pk_add_f32 %4, %4, %12\n\t"
+      "v_pk_add_f32 %5, %5, %13\n\t"
+      "v_pk_add_f32 %6, %6, %14\n\t"
+      "v_pk_add_f32 %7, %7, %15"
+      : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3]),
+        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+      : "s"(a), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+}
+
+// Two table rows per wave in registers: the one being applied and the next, in flight (four were
+// measured and bought nothing: tools/d1_tune.hip, profiles/r02_d1_*).
+template <bool SKIP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_imdct_apply(DeviceTables tb, const unsigned *__restrict__ plan_hdr, const unsigned *__restrict__ plan_rec,
+                   unsigned n_frames, unsigned ch, unsigned group_begin, unsigned n_groups, float *__restrict__ blocks) {
+  constexpr int G = 8, R = 2;
+  // block -> (frame group, channel) of this batch: workgroups are dealt round-robin over the 8 XCDs
+  // (blockIdx % 8), and channels can differ in how many coefficients they keep, so every XCD takes
+  // frame groups of ALL channels: block 8 q + x handles channel q % ch of frame group (q / ch) * 8 + x.
+  // The grid is padded to a multiple of 8 frame groups; surplus blocks leave.  (Speed only.)
+  const unsigned q_ = blockIdx.x >> 3;
+  const unsigned c = q_ % ch;
+  const unsigned fg = (q_ / ch) * 8u + (blockIdx.x & 7u);  // frame group within the batch
+  if (fg >= n_groups) return;
+  const unsigned local = fg * ch + c;
+  const unsigned fr0 = (group_begin + fg) * G;
+  const unsigned *hdr = plan_hdr + static_cast<size_t>(local) * kPlanHdrDwords;
+  const unsigned n_u = __builtin_amdgcn_readfirstlane(hdr[0]);
+  const unsigned live = __builtin_amdgcn_readfirstlane(hdr[1]);
+  if (!live) return;
+  // A wave's run time is its union length; the kernel ends with its longest wave.  Waves with long
+  // unions (the broadband frames at a stream's edges double it) take issue priority over the three
+  // waves they share a SIMD with, so that the critical path runs at full speed instead of on leftovers.
+  if (n_u >= 256) __builtin_amdgcn_s_setprio(3);
+  else if (n_u >= 208) __builtin_amdgcn_s_setprio(2);
+  else if (n_u >= 176) __builtin_amdgcn_s_setprio(1);
+  const unsigned *rec = plan_rec + static_cast<size_t>(local) * kPlanRecCap * kPlanRecDwords;
+  const unsigned col0 = static_cast<unsigned>(threadIdx.x) * 8u;  // 8 consecutive outputs per lane
+  const unsigned lane_off = col0 * 4u;
 
   d1x2 acc[G][4];
 #pragma unroll
   for (int g = 0; g < G; ++g)
 #pragma unroll
     for (int h = 0; h < 4; ++h) acc[g][h] = d1x2{0.f, 0.f};
-
-  const bool dense = mode == 3 || (mode != 2 && n_u * G <= 3u * total);  // uniform
-  if (dense) {
-    const float *tbase = tb.cos + 512;  // +2048 B, see d1_issue_table
-    const unsigned lane_off = static_cast<unsigned>(tid) * 16u;
-    const unsigned c_lds = static_cast<unsigned>(reinterpret_cast<uintptr_t>(&s_c[0]));
-    const unsigned u_lds = static_cast<unsigned>(reinterpret_cast<uintptr_t>(&s_u[0]));
-    // Registers: two table slots (the entry being applied and the next one, in flight), ONE set of
-    // the 8 coefficients (each half is re-read for the next entry right after the two row pairs that
-    // consumed it), two union indices ahead.
-    d1x4 t_lo[2], t_hi[2], clo, chi;
-    unsigned kq[2];  // at step j: union indices of entries j+1 and j+2 (rotating)
-    d1_issue_table(t_lo[0], t_hi[0], (static_cast<unsigned>(s_u[0]) << 13) + lane_off, tbase);
-    d1_issue_table(t_lo[1], t_hi[1], (static_cast<unsigned>(s_u[1]) << 13) + lane_off, tbase);
-    kq[0] = s_u[1];
-    kq[1] = s_u[2];
-    {
-      const unsigned a0 = c_lds + (static_cast<unsigned>(s_u[0]) << 5);
-      asm volatile(
-          "ds_read_b128 %0, %2\n\t"
-          "ds_read_b128 %1, %2 offset:16\n\t"
-          "s_waitcnt lgkmcnt(0)"
-          : "=&v"(clo), "=&v"(chi)
-          : "v"(a0)
-          : "memory");
-    }
-    // One entry.  S: table slot of entry J; XC: register with index J+1 (whose coefficients this step
-    // prefetches); XR: register with index J+2 (whose table row refills slot S).  On entry the LDS
-    // reads still in flight are the previous step's [index, clo, chi], of the vector-memory loads
-    // only the two of entry J+1 may be outstanding.
-#define GLC_D1_STEP(S, XC, XR, J)                                                                               \
+  d1x4 t_lo[R], t_hi[R];
+  d1u8 ca, cb, cc, cd;        // records of the pair being applied (ca, cb) and of the next pair (cc, cd)
+  unsigned ka, kb, kc, kd;
+  auto issue_tab = [&](d1x4 &lo, d1x4 &hi, unsigned koff) {
+    const unsigned long long row = reinterpret_cast<unsigned long long>(tb.cos) + koff;  // scalar ALU
+    asm volatile(
+        "global_load_dwordx4 %0, %2, %3\n\t"
+        "global_load_dwordx4 %1, %2, %3 offset:16"
+        : "=&v"(lo), "=&v"(hi)
+        : "v"(lane_off), "s"(row)
+        : "memory");
+  };
+#pragma unroll
+  for (int r = 0; r < R; ++r) issue_tab(t_lo[r], t_hi[r], __builtin_amdgcn_readfirstlane(hdr[2 + r]));  // entries 0, 1
+  // Records are fetched TWO entries at a time, a whole pair of entries ahead: scalar loads return out
+  // of order, so the only safe wait is lgkmcnt(0), which covers everything issued so far - fetching
+  // every other entry doubles the time each fetch has before it is waited for (measured on the
+  // config-2 batch: 107 -> 95 us, profiles/r02_d1_tune_real_rows.txt).  Scalar and vector operands
+  // sit in SEPARATE asm statements: LLVM treats every output of an asm that has one VGPR output as
+  // divergent, and a "divergent" row offset would be added on the vector ALU.
+#define GLC_D1_FETCH2(C0, K0, C1, K1, J)                                                                          \
   do {                                                                                                          \
-    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(1)"                                                                \
-                 : "+v"(t_lo[S]), "+v"(t_hi[S]), "+v"(clo), "+v"(kq[XC]), "+v"(kq[XR])::"memory");               \
-    const unsigned caddr = c_lds + (kq[XC] << 5);                                                               \
-    asm volatile("ds_read_u16 %0, %1" : "=&v"(kq[XC]) : "v"(u_lds + 2u * ((J) + 3u)) : "memory");               \
-    k1::mac2rows(acc[0], acc[1], clo.xy, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);                        \
-    k1::mac2rows(acc[2], acc[3], clo.zw, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);                        \
-    asm volatile("ds_read_b128 %0, %2\n\ts_waitcnt lgkmcnt(2)" : "=&v"(clo), "+v"(chi) : "v"(caddr) : "memory"); \
-    k1::mac2rows(acc[4], acc[5], chi.xy, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);                        \
-    k1::mac2rows(acc[6], acc[7], chi.zw, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);                        \
-    asm volatile("ds_read_b128 %0, %1 offset:16" : "=&v"(chi) : "v"(caddr) : "memory");                         \
-    d1_issue_table(t_lo[S], t_hi[S], (kq[XR] << 13) + lane_off, tbase);                                         \
+    const unsigned *nrec = rec + static_cast<size_t>(J) * kPlanRecDwords;                                        \
+    asm volatile(                                                                                               \
+        "s_load_dwordx8 %0, %4, 0x0\n\ts_load_dword %1, %4, 0x20\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_load_dword %3, %4, 0x60" \
+        : "=&s"(C0), "=&s"(K0), "=&s"(C1), "=&s"(K1)                                                             \
+        : "s"(nrec)                                                                                             \
+        : "memory");                                                                                            \
   } while (0)
-    unsigned j = 0;
+#define GLC_D1_WAIT2(C0, K0, C1, K1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(C0), "+s"(K0), "+s"(C1), "+s"(K1)::"memory")
+  // One entry.  S: its table slot; CC: its 8 coefficients; KC: table offset of entry J + R, whose row
+  // refills slot S.  Of the table loads only those of the R - 1 following entries may be in flight.
+#define GLC_D1_ENTRY(S, CC, KC)                                                                                  \
+  do {                                                                                                          \
+    asm volatile("s_waitcnt vmcnt(2)" : "+v"(t_lo[S]), "+v"(t_hi[S])::"memory");                                  \
+    const d1u2 p0 = CC.s01, p1 = CC.s23, p2 = CC.s45, p3 = CC.s67;                                               \
+    if (!SKIP || (p0.x | p0.y)) d1_mac2rows_s(acc[0], acc[1], p0, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw); \
+    if (!SKIP || (p1.x | p1.y)) d1_mac2rows_s(acc[2], acc[3], p1, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw); \
+    if (!SKIP || (p2.x | p2.y)) d1_mac2rows_s(acc[4], acc[5], p2, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw); \
+    if (!SKIP || (p3.x | p3.y)) d1_mac2rows_s(acc[6], acc[7], p3, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw); \
+    issue_tab(t_lo[S], t_hi[S], KC);                                                                             \
+  } while (0)
+  GLC_D1_FETCH2(ca, ka, cb, kb, 0);
+  unsigned j = 0;
 #pragma unroll 1
-    for (; j + 2 <= n_u; j += 2) {
-      GLC_D1_STEP(0, 0, 1, j);
-      GLC_D1_STEP(1, 1, 0, j + 1);
-    }
-    if (j < n_u) GLC_D1_STEP(0, 0, 1, j);
-#undef GLC_D1_STEP
-    // drain the run-ahead loads before their registers are reused
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
-                 : "+v"(t_lo[0]), "+v"(t_hi[0]), "+v"(t_lo[1]), "+v"(t_hi[1]), "+v"(clo), "+v"(chi), "+v"(kq[0]),
-                   "+v"(kq[1])::"memory");
-  } else {
-    const float *T = tb.cos + tid * 4;
-    d1x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
-    unsigned k = 0;
-    if (n_u) {
-      k = s_u[0];
-      const float *trow = T + static_cast<size_t>(k) * kFrameI;
-      t0 = *reinterpret_cast<const d1x4 *>(trow);
-      t1 = *reinterpret_cast<const d1x4 *>(trow + 1024);
-    }
-#pragma unroll 2
-    for (unsigned j = 0; j < n_u; ++j) {
-      // the next table row is in flight while this one is applied (the padded list repeats the last)
-      const unsigned kn = s_u[j + 1];
-      const float *nrow = T + static_cast<size_t>(kn) * kFrameI;
-      const d1x4 n0 = *reinterpret_cast<const d1x4 *>(nrow);
-      const d1x4 n1 = *reinterpret_cast<const d1x4 *>(nrow + 1024);
-      float cg[G];
-#pragma unroll
-      for (int g = 0; g < G; ++g) cg[g] = s_c[k * G + g];
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const float cv = cg[g];
-        if (cv != 0.0f) {  // same value in every lane: the branch is wave-uniform
-          const d1x2 c2 = {cv, cv};
-          acc[g][0] = acc[g][0] + c2 * t0.xy;
-          acc[g][1] = acc[g][1] + c2 * t0.zw;
-          acc[g][2] = acc[g][2] + c2 * t1.xy;
-          acc[g][3] = acc[g][3] + c2 * t1.zw;
-        }
+  for (; j + 4 <= n_u; j += 4) {
+    GLC_D1_WAIT2(ca, ka, cb, kb);
+    GLC_D1_FETCH2(cc, kc, cd, kd, j + 2);
+    GLC_D1_ENTRY(0, ca, ka);
+    GLC_D1_ENTRY(1, cb, kb);
+    GLC_D1_WAIT2(cc, kc, cd, kd);
+    GLC_D1_FETCH2(ca, ka, cb, kb, j + 4);
+    GLC_D1_ENTRY(0, cc, kc);
+    GLC_D1_ENTRY(1, cd, kd);
+  }
+  if (j < n_u) {  // 1..3 entries left; (ca, cb) hold entries j, j + 1
+    GLC_D1_WAIT2(ca, ka, cb, kb);
+    GLC_D1_FETCH2(cc, kc, cd, kd, j + 2);
+    GLC_D1_ENTRY(0, ca, ka);
+    if (j + 1 < n_u) {
+      GLC_D1_ENTRY(1, cb, kb);
+      if (j + 2 < n_u) {
+        GLC_D1_WAIT2(cc, kc, cd, kd);
+        GLC_D1_ENTRY(0, cc, kc);
       }
-      t0 = n0, t1 = n1, k = kn;
     }
   }
-  const float4 w0 = *reinterpret_cast<const float4 *>(tb.window + tid * 4);
-  const float4 w1 = *reinterpret_cast<const float4 *>(tb.window + 1024 + tid * 4);
+#undef GLC_D1_ENTRY
+#undef GLC_D1_FETCH2
+#undef GLC_D1_WAIT2
+  // drain the run-ahead loads before their registers are reused
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ca), "+s"(cb), "+s"(cc), "+s"(cd), "+s"(ka), "+s"(kb), "+s"(kc), "+s"(kd)::"memory");
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(t_lo[0]), "+v"(t_hi[0]), "+v"(t_lo[1]), "+v"(t_hi[1])::"memory");
+
+  const d1x4 w0 = *reinterpret_cast<const d1x4 *>(tb.window + col0), w1 = *reinterpret_cast<const d1x4 *>(tb.window + col0 + 4);
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     if (!(live & (1u << g))) continue;
-    float *out = blocks + static_cast<size_t>((fr0 + g) * ch + c) * kFrameI;
-    float4 o0, o1;  // out[i] = s*norm (:388) then *= window[i] (:674)
+    float *out = blocks + static_cast<size_t>((fr0 + g) * ch + c) * kFrameI + col0;
+    d1x4 o0, o1;  // out[i] = s*norm (:388) then *= window[i] (:674)
     o0.x = mul_rn(mul_rn(acc[g][0].x, tb.norm), w0.x); o0.y = mul_rn(mul_rn(acc[g][0].y, tb.norm), w0.y);
     o0.z = mul_rn(mul_rn(acc[g][1].x, tb.norm), w0.z); o0.w = mul_rn(mul_rn(acc[g][1].y, tb.norm), w0.w);
     o1.x = mul_rn(mul_rn(acc[g][2].x, tb.norm), w1.x); o1.y = mul_rn(mul_rn(acc[g][2].y, tb.norm), w1.y);
     o1.z = mul_rn(mul_rn(acc[g][3].x, tb.norm), w1.z); o1.w = mul_rn(mul_rn(acc[g][3].y, tb.norm), w1.w);
-    *reinterpret_cast<float4 *>(out + tid * 4) = o0;
-    *reinterpret_cast<float4 *>(out + 1024 + tid * 4) = o1;
+    *reinterpret_cast<d1x4 *>(out) = o0;
+    *reinterpret_cast<d1x4 *>(out + 4) = o1;
   }
 }
 
@@ -822,18 +858,36 @@ hipError_t launch_compact(const uint8_t *records, uint32_t M, uint32_t ch, uint6
   return hipGetLastError();
 }
 
+uint64_t imdct_plan_bytes(uint32_t groups) {
+  return static_cast<uint64_t>(groups) * (4ull * kPlanHdrDwords + static_cast<uint64_t>(kPlanRecCap) * kPlanRecDwords * 4ull);
+}
+
 hipError_t launch_imdct_rows(const DeviceTables &t, const DecodeRows &rows, uint32_t row_begin,
-                             uint32_t M, uint32_t ch, float *blocks, hipStream_t s, int variant) {
+                             uint32_t M, uint32_t ch, float *blocks, hipStream_t s, int variant, void *plan,
+                             uint32_t plan_groups) {
   if (M == 0) return hipSuccess;
   // every caller decodes whole frames; the one-row kernel is the cross-check variant (glc_debug.h)
   if (variant == 1 || ch == 0 || M % ch != 0) {
     hipLaunchKernelGGL(k_imdct_rows, dim3(M), dim3(256), 0, s, t, rows, row_begin, M, ch, blocks);
     return hipGetLastError();
   }
+  if (!plan || plan_groups < ch) return hipErrorInvalidValue;
   const uint32_t n_frames = M / ch;
   const uint32_t groups = (n_frames + 7) / 8;
-  hipLaunchKernelGGL(k_imdct_chan<8>, dim3(((groups + 7) / 8) * 8 * ch), dim3(256), 0, s, t, rows, row_begin, n_frames, ch,
-                     variant, blocks);
+  // plan + apply, in batches of whole frame groups (x all channels) through one workspace of
+  // plan_groups (frame group, channel) units
+  unsigned *hdr = static_cast<unsigned *>(plan);
+  unsigned *rec = hdr + static_cast<size_t>(plan_groups) * kPlanHdrDwords;
+  const uint32_t fg_per_batch = plan_groups / ch;
+  for (uint32_t fg0 = 0; fg0 < groups; fg0 += fg_per_batch) {
+    const uint32_t n_fg = groups - fg0 < fg_per_batch ? groups - fg0 : fg_per_batch;
+    const dim3 grid(((n_fg + 7) / 8) * 8 * ch);
+    hipLaunchKernelGGL(k_imdct_plan, dim3(n_fg * ch), dim3(256), 0, s, rows, row_begin, n_frames, ch, fg0, 2u, hdr, rec, blocks);
+    if (variant == 2)
+      hipLaunchKernelGGL(k_imdct_apply<false>, grid, dim3(256), 0, s, t, hdr, rec, n_frames, ch, fg0, n_fg, blocks);
+    else
+      hipLaunchKernelGGL(k_imdct_apply<true>, grid, dim3(256), 0, s, t, hdr, rec, n_frames, ch, fg0, n_fg, blocks);
+  }
   return hipGetLastError();
 }
 

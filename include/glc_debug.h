@@ -14,12 +14,12 @@ extern "C" {
 
 /* Which inverse-transform kernel the decode entry points of `ctx` launch (imdct_block,
  * src/codec.rs:377-390):
- *   0  shipped: k_imdct_chan<8> (8 frames of one channel per workgroup, dense or sparse path chosen
- *      per group)
+ *   0  shipped: k_imdct_plan + k_imdct_apply - 8 frames of one channel per unit over the union of
+ *      their indices; union records in global memory, coefficients fed from SGPRs, absent row pairs
+ *      skipped by scalar branches
  *   1  k_imdct_rows: one row per workgroup, no grouping (the simplest restatement)
- *   2  k_imdct_chan<8> forced onto its sparse path (per-row skip of absent indices)
- *   3  k_imdct_chan<8> forced onto its dense path (every row takes every union entry)
- * All four produce the same bits; tools/soak_decode.py checks that on random streams. */
+ *   2  plan + apply without the skip (every row takes every union entry)
+ * All three produce the same bits; tools/soak_decode.py checks that on random streams. */
 int glc_debug_set_imdct_variant(glc_ctx *ctx, int variant);
 
 #ifdef __cplusplus

@@ -15,7 +15,7 @@ import bench  # noqa: E402  (the workload generator)
 import glc_amd  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 2, 3, 1]
+variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 2, 1]
 glc_amd.lib.glc_debug_set_imdct_variant.restype = C.c_int
 glc_amd.lib.glc_debug_set_imdct_variant.argtypes = [C.c_void_p, C.c_int]
 SR, CH, NF = bench.SR, bench.CH, bench.FRAMES_PER_GPU

@@ -1,7 +1,9 @@
 """D1 (sparse IMDCT) timing on synthetic streams whose rows are correlated to a chosen degree:
 `share` = fraction of a row's coefficient indices that it has in common with every other row (the
 rest are drawn independently per row).  share = 1 is stationary tonal material, share = 0 the worst
-case for the grouped kernel.  Usage: [GLC_D1_GROUP=0|2|4|8] python tools/bench_decode_rows.py"""
+case for the grouped kernels.  Every kernel variant of include/glc_debug.h is timed (D1 alone, HIP
+events).  Usage: python tools/bench_decode_rows.py [variants, default 0,4,1]"""
+import ctypes as C
 import os
 import sys
 import time
@@ -18,6 +20,9 @@ rec = glc_amd.lib.glc_record_bytes(ch)
 hdr = rec - 4096 * ch
 rng = np.random.default_rng(3)
 dec = glc_amd.Decoder(ch, sr)
+variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 2, 1]
+glc_amd.lib.glc_debug_set_imdct_variant.restype = C.c_int
+glc_amd.lib.glc_debug_set_imdct_variant.argtypes = [C.c_void_p, C.c_int]
 for share in (1.0, 0.75, 0.5, 0.0):
     common = rng.choice(1024, int(round(nnz * share)), replace=False)
     rest = np.setdiff1d(np.arange(1024), common)
@@ -30,14 +35,15 @@ for share in (1.0, 0.75, 0.5, 0.0):
             buf[f, 8 + 8 * c:12 + 8 * c] = np.frombuffer(np.float32(0.3).tobytes(), np.uint8)
             buf[f, 12 + 8 * c:16 + 8 * c] = np.frombuffer(np.uint32(nnz).tobytes(), np.uint8)
     ea = glc_amd.EncodedAudio.from_records(sr, nf * 1024 * ch, ch, buf.reshape(-1))
-    d_all = torch.empty((nf + 1) * 1024 * ch, dtype=torch.float32, device="cuda")
-    for _ in range(3):
-        dec.decode_device(ea, d_all.data_ptr(), d_all.numel())
-    dec.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(20):
-        dec.decode_device(ea, d_all.data_ptr(), d_all.numel())
-    dec.synchronize()
-    ms = (time.perf_counter() - t0) / 20 * 1e3
-    print(f"group {os.environ.get('GLC_D1_GROUP', 'default')}: shared indices {share:4.2f}  decode_device {ms:6.3f} ms per {nf} frames "
-          f"(checksum {float(d_all.double().abs().sum()):.6e})", flush=True)
+    d_blk = torch.empty((nf * ch, 2048), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    out = []
+    for v in variants:
+        assert glc_amd.lib.glc_debug_set_imdct_variant(dec._h, v) == 0
+        for _ in range(10):
+            dec.imdct_device(ea, 0, nf, d_blk.data_ptr())
+        dec.timer_begin()
+        for _ in range(20):
+            dec.imdct_device(ea, 0, nf, d_blk.data_ptr())
+        out.append(f"variant {v}: {dec.timer_end() / 20 * 1e3:7.1f} us")
+    print(f"shared indices {share:4.2f}  D1 per {nf} stereo frames (nnz/row {nnz}):  " + "   ".join(out), flush=True)

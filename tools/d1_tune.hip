@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -431,6 +432,422 @@ void k_chan16(const float *T, const float *win, float norm, Rows rows, unsigned 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Variant family C: plan + apply.
+//   k_plan   one workgroup per (group of 8 frames, channel): dequantises the rows into LDS, builds
+//            the ascending union and writes it to global memory as 64-byte records
+//            {8 coefficients (0 = absent), byte offset of the table row of entry j+2}, plus a
+//            header {n_u, live rows, offsets of entries 0 and 1}.
+//   k_apply  no LDS, no barrier: every wave owns 8 rows x (64 lanes x COLS columns).  The record of
+//            the next entry arrives by scalar loads (s_load_dwordx8 + s_load_dword) a whole entry
+//            ahead, the coefficient pairs feed v_pk_mul_f32 straight from SGPRs (broadcast via
+//            op_sel), the table row of the entry after next is in flight by global_load_dwordx4 with
+//            an SGPR base.  The vector ALU executes the 64 packed multiplies / adds per entry and
+//            nothing else; a row pair whose two coefficients are both absent is skipped by a scalar
+//            branch.
+// ------------------------------------------------------------------------------------------
+typedef unsigned u8v __attribute__((ext_vector_type(8)));
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+constexpr unsigned kRecDwords = 16, kRecCap = 1024 + 4;
+
+__global__ __launch_bounds__(256) void k_plan(Rows rows, unsigned n_frames, unsigned ch, unsigned *plan_hdr, unsigned *plan_rec) {
+  constexpr int G = 8;
+  __shared__ __attribute__((aligned(16))) float s_c[kHopI * G];
+  __shared__ unsigned s_mask[kHopI / 32];
+  __shared__ unsigned short s_u[kHopI + 8];
+  __shared__ unsigned s_wsum[4];
+  const int tid = threadIdx.x;
+  const unsigned grp = blockIdx.x;
+  const unsigned c = grp % ch;
+  const unsigned fr0 = (grp / ch) * G;
+  for (int i = tid; i < kHopI * G; i += 256) s_c[i] = 0.0f;
+  if (tid < kHopI / 32) s_mask[tid] = 0u;
+  __syncthreads();
+  unsigned live = 0;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const unsigned fr = fr0 + g;
+    if (fr >= n_frames) continue;
+    const unsigned m = fr * ch + c;
+    live |= 1u << g;
+    const unsigned long long p0 = rows.begin[m];
+    const unsigned n = rows.cnt[m];
+    const float scale = fmaxf(rows.scale[m], 1e-12f);
+    for (unsigned j = tid; j < n; j += 256) {
+      const unsigned pr = rows.pairs[p0 + j];
+      const unsigned idx = pr & 0xFFFFu;
+      s_c[idx * G + g] = mul_rn(static_cast<float>(static_cast<short>(pr >> 16)) / 32768.0f, scale);
+      atomicOr(&s_mask[idx >> 5], 1u << (idx & 31));
+    }
+  }
+  __syncthreads();
+  const unsigned nib = (s_mask[tid >> 3] >> ((tid & 7) * 4)) & 0xFu;
+  const unsigned cnt = __popc(nib);
+  unsigned incl = cnt;
+  const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) s_wsum[w] = incl;
+  __syncthreads();
+  unsigned base = 0, n_u = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned v = s_wsum[i];
+    if (i < w) base += v;
+    n_u += v;
+  }
+  {
+    unsigned pos = base + incl - cnt;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (nib & (1u << b)) s_u[pos++] = static_cast<unsigned short>(tid * 4 + b);
+  }
+  __syncthreads();
+  if (tid < 8) s_u[n_u + tid] = n_u ? s_u[n_u - 1] : static_cast<unsigned short>(0);
+  __syncthreads();
+  unsigned *rec = plan_rec + static_cast<size_t>(grp) * kRecCap * kRecDwords;
+  for (unsigned j = tid; j < n_u; j += 256) {
+    const unsigned k = s_u[j];
+    const d1x4 lo = *reinterpret_cast<const d1x4 *>(&s_c[k * G]), hi = *reinterpret_cast<const d1x4 *>(&s_c[k * G + 4]);
+    d1x4 *dst = reinterpret_cast<d1x4 *>(rec + static_cast<size_t>(j) * kRecDwords);
+    dst[0] = lo;
+    dst[1] = hi;
+    rec[static_cast<size_t>(j) * kRecDwords + 8] = static_cast<unsigned>(s_u[j + 2]) << 13;
+  }
+  if (tid == 0) {
+    unsigned *h = plan_hdr + grp * 4;
+    h[0] = n_u;
+    h[1] = live;
+    h[2] = static_cast<unsigned>(s_u[0]) << 13;
+    h[3] = static_cast<unsigned>(s_u[1]) << 13;
+  }
+}
+
+// rows (r, r+1) x 8 columns with the coefficient pair in SGPRs
+__device__ __forceinline__ void mac2rows_s(d1x2 (&c0)[4], d1x2 (&c1)[4], u2v a, d1x2 b0, d1x2 b1, d1x2 b2, d1x2 b3) {
+  d1x2 t0, t1, t2, t3, t4, t5, t6, t7;
+  asm volatile(
+      "v_pk_mul_f32 %8, %16, %17 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %9, %16, %18 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %10, %16, %19 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %11, %16, %20 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %12, %16, %17 op_sel:[1,0]\n\t"
+      "v_pk_mul_f32 %13, %16, %18 op_sel:[1,0]\n\t"
+      "v_pk_mul_f32 %14, %16, %19 op_sel:[1,0]\n\t"
+      "v_pk_mul_f32 %15, %16, %20 op_sel:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, %8\n\t"
+      "v_pk_add_f32 %1, %1, %9\n\t"
+      "v_pk_add_f32 %2, %2, %10\n\t"
+      "v_pk_add_f32 %3, %3, %11\n\t"
+      "v_pk_add_f32 %4, %4, %12\n\t"
+      "v_pk_add_f32 %5, %5, %13\n\t"
+      "v_pk_add_f32 %6, %6, %14\n\t"
+      "v_pk_add_f32 %7, %7, %15"
+      : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3]),
+        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+      : "s"(a), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+}
+
+template <bool SKIP, bool NT, int MINW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
+void k_apply(const float *T, const float *win, float norm, const unsigned *plan_hdr, const unsigned *plan_rec,
+             unsigned n_frames, unsigned ch, float *blocks) {
+  constexpr int G = 8;
+  const unsigned q_ = blockIdx.x >> 3;
+  const unsigned c = q_ % ch;
+  const unsigned fgrp = (q_ / ch) * 8u + (blockIdx.x & 7u);
+  const unsigned fr0 = fgrp * G;
+  if (fr0 >= n_frames) return;
+  const unsigned grp = fgrp * ch + c;
+  const unsigned *hdr = plan_hdr + grp * 4;
+  const unsigned n_u = __builtin_amdgcn_readfirstlane(hdr[0]);
+  const unsigned live = __builtin_amdgcn_readfirstlane(hdr[1]);
+  const unsigned k0 = __builtin_amdgcn_readfirstlane(hdr[2]), k1 = __builtin_amdgcn_readfirstlane(hdr[3]);
+  if (!live) return;
+  const unsigned *rec = plan_rec + static_cast<size_t>(grp) * kRecCap * kRecDwords;
+  const int tid = threadIdx.x;
+  const unsigned col0 = static_cast<unsigned>(tid) * 8u;  // 8 consecutive outputs per lane: [col0, col0 + 8)
+  const unsigned lane_off = col0 * 4u;
+
+  d1x2 acc[G][4];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) acc[g][h] = d1x2{0.f, 0.f};
+  d1x4 t_lo[2], t_hi[2];
+  u8v ca, cb;
+  unsigned ka, kb;
+  auto issue_tab = [&](d1x4 &lo, d1x4 &hi, unsigned koff) {
+    const unsigned long long row = reinterpret_cast<unsigned long long>(T) + koff;  // SALU: base of table row k
+    asm volatile(
+        "global_load_dwordx4 %0, %2, %3\n\t"
+        "global_load_dwordx4 %1, %2, %3 offset:16"
+        : "=&v"(lo), "=&v"(hi)
+        : "v"(lane_off), "s"(row)
+        : "memory");
+  };
+  issue_tab(t_lo[0], t_hi[0], k0);
+  issue_tab(t_lo[1], t_hi[1], k1);
+  asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(ca), "=&s"(ka) : "s"(rec) : "memory");
+  // one entry: S = table slot, (CC, KC) = this entry's record, (CN, KN) = the other record set, refilled
+  // with the record of the NEXT entry at the top of this step (it has the whole step to arrive)
+#define STEPC(S, CC, KC, CN, KN, J)                                                                            \
+  do {                                                                                                        \
+    /* scalar and vector operands in SEPARATE asm statements: LLVM marks every output of an asm that has */    \
+    /* one VGPR output as divergent, and a "divergent" offset would be added on the vector ALU */             \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(CC), "+s"(KC)::"memory");                                        \
+    asm volatile("s_waitcnt vmcnt(2)" : "+v"(t_lo[S]), "+v"(t_hi[S])::"memory");                                \
+    {                                                                                                         \
+      const unsigned *nrec = rec + static_cast<size_t>((J) + 1) * kRecDwords;                                  \
+      asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x20" : "=&s"(CN), "=&s"(KN) : "s"(nrec) : "memory"); \
+    }                                                                                                         \
+    const u2v p0 = CC.s01, p1 = CC.s23, p2 = CC.s45, p3 = CC.s67;                                              \
+    if (!SKIP || (p0.x | p0.y)) mac2rows_s(acc[0], acc[1], p0, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);  \
+    if (!SKIP || (p1.x | p1.y)) mac2rows_s(acc[2], acc[3], p1, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);  \
+    if (!SKIP || (p2.x | p2.y)) mac2rows_s(acc[4], acc[5], p2, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);  \
+    if (!SKIP || (p3.x | p3.y)) mac2rows_s(acc[6], acc[7], p3, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);  \
+    issue_tab(t_lo[S], t_hi[S], KC); /* entry J + 2 */                                                         \
+  } while (0)
+  unsigned j = 0;
+#pragma unroll 1
+  for (; j + 2 <= n_u; j += 2) {
+    STEPC(0, ca, ka, cb, kb, j);
+    STEPC(1, cb, kb, ca, ka, j + 1);
+  }
+  if (j < n_u) STEPC(0, ca, ka, cb, kb, j);
+#undef STEPC
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ca), "+s"(cb), "+s"(ka), "+s"(kb)::"memory");
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(t_lo[0]), "+v"(t_hi[0]), "+v"(t_lo[1]), "+v"(t_hi[1])::"memory");
+
+  const d1x4 w0 = *reinterpret_cast<const d1x4 *>(win + col0), w1 = *reinterpret_cast<const d1x4 *>(win + col0 + 4);
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    if (!(live & (1u << g))) continue;
+    float *out = blocks + static_cast<size_t>((fr0 + g) * ch + c) * kFrameI + col0;
+    d1x4 o0, o1;
+    o0.x = mul_rn(mul_rn(acc[g][0].x, norm), w0.x); o0.y = mul_rn(mul_rn(acc[g][0].y, norm), w0.y);
+    o0.z = mul_rn(mul_rn(acc[g][1].x, norm), w0.z); o0.w = mul_rn(mul_rn(acc[g][1].y, norm), w0.w);
+    o1.x = mul_rn(mul_rn(acc[g][2].x, norm), w1.x); o1.y = mul_rn(mul_rn(acc[g][2].y, norm), w1.y);
+    o1.z = mul_rn(mul_rn(acc[g][3].x, norm), w1.z); o1.w = mul_rn(mul_rn(acc[g][3].y, norm), w1.w);
+    if (NT) {
+      __builtin_nontemporal_store(o0, reinterpret_cast<d1x4 *>(out));
+      __builtin_nontemporal_store(o1, reinterpret_cast<d1x4 *>(out + 4));
+    } else {
+      *reinterpret_cast<d1x4 *>(out) = o0;
+      *reinterpret_cast<d1x4 *>(out + 4) = o1;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Variant C2: apply with the records fetched TWO entries at a time, a whole pair of entries ahead
+// (scalar loads return out of order, so the only safe wait is lgkmcnt(0): fetching every other
+// entry doubles the slack of each wait), otherwise k_apply.
+// ------------------------------------------------------------------------------------------
+template <bool SKIP, int MINW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
+void k_apply_pair(const float *T, const float *win, float norm, const unsigned *plan_hdr, const unsigned *plan_rec,
+                  unsigned n_frames, unsigned ch, float *blocks) {
+  constexpr int G = 8;
+  const unsigned q_ = blockIdx.x >> 3;
+  const unsigned c = q_ % ch;
+  const unsigned fgrp = (q_ / ch) * 8u + (blockIdx.x & 7u);
+  const unsigned fr0 = fgrp * G;
+  if (fr0 >= n_frames) return;
+  const unsigned grp = fgrp * ch + c;
+  const unsigned *hdr = plan_hdr + grp * 4;
+  const unsigned n_u = __builtin_amdgcn_readfirstlane(hdr[0]);
+  const unsigned live = __builtin_amdgcn_readfirstlane(hdr[1]);
+  const unsigned k0 = __builtin_amdgcn_readfirstlane(hdr[2]), k1 = __builtin_amdgcn_readfirstlane(hdr[3]);
+  if (!live) return;
+  const unsigned *rec = plan_rec + static_cast<size_t>(grp) * kRecCap * kRecDwords;
+  const unsigned col0 = static_cast<unsigned>(threadIdx.x) * 8u;
+  const unsigned lane_off = col0 * 4u;
+  d1x2 acc[G][4];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) acc[g][h] = d1x2{0.f, 0.f};
+  d1x4 t_lo[2], t_hi[2];
+  u8v ca, cb, cc, cd;
+  unsigned ka, kb, kc, kd;
+  auto issue_tab = [&](d1x4 &lo, d1x4 &hi, unsigned koff) {
+    const unsigned long long row = reinterpret_cast<unsigned long long>(T) + koff;
+    asm volatile(
+        "global_load_dwordx4 %0, %2, %3\n\t"
+        "global_load_dwordx4 %1, %2, %3 offset:16"
+        : "=&v"(lo), "=&v"(hi)
+        : "v"(lane_off), "s"(row)
+        : "memory");
+  };
+  issue_tab(t_lo[0], t_hi[0], k0);
+  issue_tab(t_lo[1], t_hi[1], k1);
+  asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dword %1, %4, 0x20\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_load_dword %3, %4, 0x60\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(ca), "=&s"(ka), "=&s"(cb), "=&s"(kb) : "s"(rec) : "memory");
+#define ENTRYP(S, CC_, KC_)                                                                                   \
+  do {                                                                                                        \
+    asm volatile("s_waitcnt vmcnt(2)" : "+v"(t_lo[S]), "+v"(t_hi[S])::"memory");                                \
+    const u2v p0 = CC_.s01, p1 = CC_.s23, p2 = CC_.s45, p3 = CC_.s67;                                          \
+    if (!SKIP || (p0.x | p0.y)) mac2rows_s(acc[0], acc[1], p0, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);  \
+    if (!SKIP || (p1.x | p1.y)) mac2rows_s(acc[2], acc[3], p1, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);  \
+    if (!SKIP || (p2.x | p2.y)) mac2rows_s(acc[4], acc[5], p2, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);  \
+    if (!SKIP || (p3.x | p3.y)) mac2rows_s(acc[6], acc[7], p3, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);  \
+    issue_tab(t_lo[S], t_hi[S], KC_);                                                                          \
+  } while (0)
+#define FETCH2(C0, K0, C1, K1, J)                                                                             \
+  do {                                                                                                        \
+    const unsigned *nrec = rec + static_cast<size_t>(J) * kRecDwords;                                          \
+    asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dword %1, %4, 0x20\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_load_dword %3, %4, 0x60" \
+                 : "=&s"(C0), "=&s"(K0), "=&s"(C1), "=&s"(K1) : "s"(nrec) : "memory");                          \
+  } while (0)
+#define WAIT2(C0, K0, C1, K1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(C0), "+s"(K0), "+s"(C1), "+s"(K1)::"memory")
+  unsigned j = 0;
+#pragma unroll 1
+  for (; j + 4 <= n_u; j += 4) {
+    WAIT2(ca, ka, cb, kb);
+    FETCH2(cc, kc, cd, kd, j + 2);
+    ENTRYP(0, ca, ka);
+    ENTRYP(1, cb, kb);
+    WAIT2(cc, kc, cd, kd);
+    FETCH2(ca, ka, cb, kb, j + 4);
+    ENTRYP(0, cc, kc);
+    ENTRYP(1, cd, kd);
+  }
+  if (j < n_u) {  // 1..3 entries left: (ca, cb) hold j, j+1
+    WAIT2(ca, ka, cb, kb);
+    FETCH2(cc, kc, cd, kd, j + 2);
+    ENTRYP(0, ca, ka);
+    if (j + 1 < n_u) {
+      ENTRYP(1, cb, kb);
+      if (j + 2 < n_u) {
+        WAIT2(cc, kc, cd, kd);
+        ENTRYP(0, cc, kc);
+      }
+    }
+  }
+#undef ENTRYP
+#undef FETCH2
+#undef WAIT2
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ca), "+s"(cb), "+s"(cc), "+s"(cd), "+s"(ka), "+s"(kb), "+s"(kc), "+s"(kd)::"memory");
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(t_lo[0]), "+v"(t_hi[0]), "+v"(t_lo[1]), "+v"(t_hi[1])::"memory");
+  const d1x4 w0 = *reinterpret_cast<const d1x4 *>(win + col0), w1 = *reinterpret_cast<const d1x4 *>(win + col0 + 4);
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    if (!(live & (1u << g))) continue;
+    float *out = blocks + static_cast<size_t>((fr0 + g) * ch + c) * kFrameI + col0;
+    d1x4 o0, o1;
+    o0.x = mul_rn(mul_rn(acc[g][0].x, norm), w0.x); o0.y = mul_rn(mul_rn(acc[g][0].y, norm), w0.y);
+    o0.z = mul_rn(mul_rn(acc[g][1].x, norm), w0.z); o0.w = mul_rn(mul_rn(acc[g][1].y, norm), w0.w);
+    o1.x = mul_rn(mul_rn(acc[g][2].x, norm), w1.x); o1.y = mul_rn(mul_rn(acc[g][2].y, norm), w1.y);
+    o1.z = mul_rn(mul_rn(acc[g][3].x, norm), w1.z); o1.w = mul_rn(mul_rn(acc[g][3].y, norm), w1.w);
+    *reinterpret_cast<d1x4 *>(out) = o0;
+    *reinterpret_cast<d1x4 *>(out + 4) = o1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Variant D: apply with 4 outputs per lane and row (32 accumulators, ~60 VGPRs): twice as many,
+// half as long waves - 8 per SIMD - so that the phase in which a SIMD is down to its last wave or
+// two is a smaller part of the kernel.  Two workgroups (column halves) per group.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mac2rows4_s(d1x2 (&c0)[2], d1x2 (&c1)[2], d1x2 (&c2)[2], d1x2 (&c3)[2], u2v a01, u2v a23,
+                                            d1x2 b0, d1x2 b1) {
+  d1x2 t0, t1, t2, t3, t4, t5, t6, t7;
+  asm volatile(
+      "v_pk_mul_f32 %8, %16, %18 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %9, %16, %19 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %10, %16, %18 op_sel:[1,0]\n\t"
+      "v_pk_mul_f32 %11, %16, %19 op_sel:[1,0]\n\t"
+      "v_pk_mul_f32 %12, %17, %18 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %13, %17, %19 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %14, %17, %18 op_sel:[1,0]\n\t"
+      "v_pk_mul_f32 %15, %17, %19 op_sel:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, %8\n\t"
+      "v_pk_add_f32 %1, %1, %9\n\t"
+      "v_pk_add_f32 %2, %2, %10\n\t"
+      "v_pk_add_f32 %3, %3, %11\n\t"
+      "v_pk_add_f32 %4, %4, %12\n\t"
+      "v_pk_add_f32 %5, %5, %13\n\t"
+      "v_pk_add_f32 %6, %6, %14\n\t"
+      "v_pk_add_f32 %7, %7, %15"
+      : "+v"(c0[0]), "+v"(c0[1]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c2[0]), "+v"(c2[1]), "+v"(c3[0]), "+v"(c3[1]),
+        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+      : "s"(a01), "s"(a23), "v"(b0), "v"(b1));
+}
+
+template <bool SKIP, int MINW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
+void k_apply4(const float *T, const float *win, float norm, const unsigned *plan_hdr, const unsigned *plan_rec,
+              unsigned n_frames, unsigned ch, float *blocks) {
+  constexpr int G = 8;
+  const unsigned half = blockIdx.x & 1u;
+  const unsigned b2 = blockIdx.x >> 1;
+  const unsigned q_ = b2 >> 3;
+  const unsigned c = q_ % ch;
+  const unsigned fgrp = (q_ / ch) * 8u + (b2 & 7u);
+  const unsigned fr0 = fgrp * G;
+  if (fr0 >= n_frames) return;
+  const unsigned grp = fgrp * ch + c;
+  const unsigned *hdr = plan_hdr + grp * 4;
+  const unsigned n_u = __builtin_amdgcn_readfirstlane(hdr[0]);
+  const unsigned live = __builtin_amdgcn_readfirstlane(hdr[1]);
+  const unsigned k0 = __builtin_amdgcn_readfirstlane(hdr[2]), k1 = __builtin_amdgcn_readfirstlane(hdr[3]);
+  if (!live) return;
+  const unsigned *rec = plan_rec + static_cast<size_t>(grp) * kRecCap * kRecDwords;
+  const unsigned col0 = half * 1024u + static_cast<unsigned>(threadIdx.x) * 4u;
+  const unsigned lane_off = col0 * 4u;
+  d1x2 acc[G][2];
+#pragma unroll
+  for (int g = 0; g < G; ++g) acc[g][0] = acc[g][1] = d1x2{0.f, 0.f};
+  d1x4 tt[2];
+  u8v ca, cb;
+  unsigned ka, kb;
+  auto issue_tab = [&](d1x4 &t, unsigned koff) {
+    const unsigned long long row = reinterpret_cast<unsigned long long>(T) + koff;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(t) : "v"(lane_off), "s"(row) : "memory");
+  };
+  issue_tab(tt[0], k0);
+  issue_tab(tt[1], k1);
+  asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)" : "=&s"(ca), "=&s"(ka) : "s"(rec) : "memory");
+#define STEP4(S, CC_, KC_, CN_, KN_, J)                                                                        \
+  do {                                                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(CC_), "+s"(KC_)::"memory");                                      \
+    asm volatile("s_waitcnt vmcnt(1)" : "+v"(tt[S])::"memory");                                                 \
+    {                                                                                                         \
+      const unsigned *nrec = rec + static_cast<size_t>((J) + 1) * kRecDwords;                                  \
+      asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x20" : "=&s"(CN_), "=&s"(KN_) : "s"(nrec) : "memory"); \
+    }                                                                                                         \
+    const u2v p0 = CC_.s01, p1 = CC_.s23, p2 = CC_.s45, p3 = CC_.s67;                                          \
+    if (!SKIP || (p0.x | p0.y | p1.x | p1.y)) mac2rows4_s(acc[0], acc[1], acc[2], acc[3], p0, p1, tt[S].xy, tt[S].zw); \
+    if (!SKIP || (p2.x | p2.y | p3.x | p3.y)) mac2rows4_s(acc[4], acc[5], acc[6], acc[7], p2, p3, tt[S].xy, tt[S].zw); \
+    issue_tab(tt[S], KC_);                                                                                     \
+  } while (0)
+  unsigned j = 0;
+#pragma unroll 1
+  for (; j + 2 <= n_u; j += 2) {
+    STEP4(0, ca, ka, cb, kb, j);
+    STEP4(1, cb, kb, ca, ka, j + 1);
+  }
+  if (j < n_u) STEP4(0, ca, ka, cb, kb, j);
+#undef STEP4
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ca), "+s"(cb), "+s"(ka), "+s"(kb)::"memory");
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(tt[0]), "+v"(tt[1])::"memory");
+  const d1x4 w0 = *reinterpret_cast<const d1x4 *>(win + col0);
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    if (!(live & (1u << g))) continue;
+    float *out = blocks + static_cast<size_t>((fr0 + g) * ch + c) * kFrameI + col0;
+    d1x4 o0;
+    o0.x = mul_rn(mul_rn(acc[g][0].x, norm), w0.x); o0.y = mul_rn(mul_rn(acc[g][0].y, norm), w0.y);
+    o0.z = mul_rn(mul_rn(acc[g][1].x, norm), w0.z); o0.w = mul_rn(mul_rn(acc[g][1].y, norm), w0.w);
+    *reinterpret_cast<d1x4 *>(out) = o0;
+  }
+}
+
 __global__ void k_count_diff(const unsigned *a, const unsigned *b, size_t n, unsigned long long *bad) {
   unsigned long long local = 0;
   for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) local += a[i] != b[i];
@@ -438,8 +855,19 @@ __global__ void k_count_diff(const unsigned *a, const unsigned *b, size_t n, uns
 }
 
 int main(int argc, char **argv) {
-  const unsigned nf = argc > 1 ? atoi(argv[1]) : 4096;
-  const unsigned ch = argc > 2 ? atoi(argv[2]) : 2;
+  // `d1_tune file [path] [reps]`: rows written by tools/dump_d1_rows.py (the real config-2 batch)
+  const bool from_file = argc > 1 && std::string(argv[1]) == "file";
+  unsigned file_hdr[4] = {0, 0, 0, 0};
+  FILE *fp = nullptr;
+  if (from_file) {
+    fp = std::fopen(argc > 2 ? argv[2] : "build/d1_rows.bin", "rb");
+    if (!fp || std::fread(file_hdr, 4, 4, fp) != 4) {
+      printf("cannot read the rows file\n");
+      return 1;
+    }
+  }
+  const unsigned nf = from_file ? file_hdr[0] : (argc > 1 ? atoi(argv[1]) : 4096);
+  const unsigned ch = from_file ? file_hdr[1] : (argc > 2 ? atoi(argv[2]) : 2);
   const int reps = argc > 3 ? atoi(argv[3]) : 20;
   const unsigned union_mean = argc > 4 ? atoi(argv[4]) : 155;
   const double keep = argc > 5 ? atof(argv[5]) : 0.735;
@@ -454,7 +882,7 @@ int main(int argc, char **argv) {
   std::vector<float> scale(M);
   std::vector<std::vector<unsigned>> row_idx(M);
   std::uniform_real_distribution<double> U(0.0, 1.0);
-  for (unsigned c = 0; c < ch; ++c)
+  for (unsigned c = 0; c < ch && !from_file; ++c)
     for (unsigned f0 = 0; f0 < nf; f0 += 16) {
       std::vector<unsigned> all(1024);
       for (unsigned i = 0; i < 1024; ++i) all[i] = i;
@@ -474,7 +902,20 @@ int main(int argc, char **argv) {
       }
     }
   unsigned long long total = 0;
-  for (unsigned m = 0; m < M; ++m) {
+  if (from_file) {
+    pairs.resize(file_hdr[3]);
+    if (std::fread(begin.data(), 8, M, fp) != M || std::fread(cnt.data(), 4, M, fp) != M ||
+        std::fread(scale.data(), 4, M, fp) != M || std::fread(pairs.data(), 4, pairs.size(), fp) != pairs.size()) {
+      printf("short rows file\n");
+      return 1;
+    }
+    std::fclose(fp);
+    for (unsigned m = 0; m < M; ++m) {
+      total += cnt[m];
+      for (unsigned j = 0; j < cnt[m]; ++j) row_idx[m].push_back(pairs[begin[m] + j] & 0xFFFFu);
+    }
+  }
+  for (unsigned m = 0; m < M && !from_file; ++m) {
     begin[m] = pairs.size();
     cnt[m] = static_cast<unsigned>(row_idx[m].size());
     scale[m] = static_cast<float>(0.01 + U(rng));
@@ -506,12 +947,23 @@ int main(int argc, char **argv) {
 
   std::vector<float> hT(1024 * 2048), hw(2048);
   for (auto &v : hT) v = static_cast<float>(U(rng) * 2 - 1);
+  if (from_file)  // the codec's own table (values matter for power, hence clocks)
+    for (unsigned k = 0; k < 1024; ++k)
+      for (unsigned i = 0; i < 2048; ++i)
+        hT[size_t(k) * 2048 + i] = cosf((3.14159265358979f / 1024.f) * (float(i) + 0.5f + 512.f) * (float(k) + 0.5f));
   for (auto &v : hw) v = static_cast<float>(U(rng));
   float *dT, *dw, *d_ref, *d_out;
   unsigned *d_pairs, *d_cnt;
   unsigned long long *d_begin, *d_bad;
   float *d_scale;
-  CHECK(hipMalloc(&dT, hT.size() * 4));
+  // D1_TUNE_TABLE_OFFSET=<bytes>: place the table at that offset inside a larger allocation (the
+  // library's table sits 8 MiB into the context's constant block)
+  const size_t t_off = getenv("D1_TUNE_TABLE_OFFSET") ? strtoull(getenv("D1_TUNE_TABLE_OFFSET"), nullptr, 0) : 0;
+  {
+    char *raw = nullptr;
+    CHECK(hipMalloc(&raw, hT.size() * 4 + t_off + 4096));
+    dT = reinterpret_cast<float *>(raw + t_off);
+  }
   CHECK(hipMalloc(&dw, hw.size() * 4));
   CHECK(hipMalloc(&d_ref, size_t(M) * 2048 * 4));
   CHECK(hipMalloc(&d_out, size_t(M) * 2048 * 4));
@@ -534,19 +986,22 @@ int main(int argc, char **argv) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
+  hipStream_t st = 0;  // D1_TUNE_STREAM=1: a non-blocking stream like the library's, instead of the null stream
+  if (getenv("D1_TUNE_STREAM")) CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   auto run = [&](const char *name, bool exact, auto launch) {
     CHECK(hipMemset(d_out, 0xFF, size_t(M) * 2048 * 4));
     for (int i = 0; i < 5; ++i) launch();
-    CHECK(hipEventRecord(e0, 0));
+    CHECK(hipEventRecord(e0, st));
     for (int i = 0; i < reps; ++i) launch();
-    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventRecord(e1, st));
     CHECK(hipEventSynchronize(e1));
     float ms = 0;
     CHECK(hipEventElapsedTime(&ms, e0, e1));
     ms /= reps;
     unsigned long long bad = 0;
+    CHECK(hipStreamSynchronize(st));
     CHECK(hipMemset(d_bad, 0, 8));
-    hipLaunchKernelGGL(k_count_diff, dim3(2048), dim3(256), 0, 0, reinterpret_cast<const unsigned *>(d_ref),
+    hipLaunchKernelGGL(k_count_diff, dim3(2048), dim3(256), 0, st, reinterpret_cast<const unsigned *>(d_ref),
                        reinterpret_cast<const unsigned *>(d_out), size_t(M) * 2048, d_bad);
     CHECK(hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost));
     const double tf = double(total) * 2048 * 2 / (ms * 1e-3) / 1e12;
@@ -558,9 +1013,9 @@ int main(int argc, char **argv) {
   const unsigned g8 = ((nf + 7) / 8) * ch, g16 = ((nf + 15) / 16) * ch;
 #define A(DEPTH, NT, ABL, MINW)                                                                            \
   run("A depth" #DEPTH " nt" #NT " abl" #ABL " w" #MINW, ABL == 0, [&] {                                    \
-    hipLaunchKernelGGL((k_chan<DEPTH, NT, ABL, MINW>), dim3(g8), dim3(256), 0, 0, dT, dw, norm, R, nf, ch, d_out); \
+    hipLaunchKernelGGL((k_chan<DEPTH, NT, ABL, MINW>), dim3(g8), dim3(256), 0, st, dT, dw, norm, R, nf, ch, d_out); \
   })
-  run("reference (one output per lane)", true, [&] { hipLaunchKernelGGL(k_ref, dim3(M), dim3(256), 0, 0, dT, dw, norm, R, M, d_out); });
+  run("reference (one output per lane)", true, [&] { hipLaunchKernelGGL(k_ref, dim3(M), dim3(256), 0, st, dT, dw, norm, R, M, d_out); });
   A(1, false, 0, 4);
   A(1, true, 0, 4);
   A(2, false, 0, 4);
@@ -569,7 +1024,40 @@ int main(int argc, char **argv) {
   A(1, false, 1, 4);
   A(1, false, 2, 4);
   A(1, false, 3, 4);
-  run("B G16 nt0 w4", true, [&] { hipLaunchKernelGGL((k_chan16<false, 4>), dim3(g16), dim3(512), 0, 0, dT, dw, norm, R, nf, ch, d_out); });
-  run("B G16 nt1 w4", true, [&] { hipLaunchKernelGGL((k_chan16<true, 4>), dim3(g16), dim3(512), 0, 0, dT, dw, norm, R, nf, ch, d_out); });
+  unsigned *d_hdr, *d_prec;
+  CHECK(hipMalloc(&d_hdr, size_t(g8) * 4 * 4));
+  CHECK(hipMalloc(&d_prec, size_t(g8) * kRecCap * kRecDwords * 4));
+  const unsigned gridC = ((((nf + 7) / 8) + 7) / 8) * 8 * ch;
+  run("C plan only", false, [&] { hipLaunchKernelGGL(k_plan, dim3(g8), dim3(256), 0, st, R, nf, ch, d_hdr, d_prec); });
+#define CRUN(SKIP, NT, MINW)                                                                                     \
+  run("C plan + apply skip" #SKIP " nt" #NT " w" #MINW, true, [&] {                                              \
+    hipLaunchKernelGGL(k_plan, dim3(g8), dim3(256), 0, st, R, nf, ch, d_hdr, d_prec);                              \
+    hipLaunchKernelGGL((k_apply<SKIP, NT, MINW>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out); \
+  })
+  CRUN(false, false, 4);
+  CRUN(true, false, 4);
+  CRUN(true, true, 4);
+  run("C2 plan + apply_pair skip1 w4", true, [&] {
+    hipLaunchKernelGGL(k_plan, dim3(g8), dim3(256), 0, st, R, nf, ch, d_hdr, d_prec);
+    hipLaunchKernelGGL((k_apply_pair<true, 4>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out);
+  });
+  run("C2 apply_pair alone skip1 w4", true, [&] {
+    hipLaunchKernelGGL((k_apply_pair<true, 4>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out);
+  });
+  run("D plan + apply4 (4 cols/lane) skip1 w8", true, [&] {
+    hipLaunchKernelGGL(k_plan, dim3(g8), dim3(256), 0, st, R, nf, ch, d_hdr, d_prec);
+    hipLaunchKernelGGL((k_apply4<true, 8>), dim3(gridC * 2), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out);
+  });
+  run("D apply4 alone skip1 w8", true, [&] {
+    hipLaunchKernelGGL((k_apply4<true, 8>), dim3(gridC * 2), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out);
+  });
+  run("D apply4 alone skip0 w8", true, [&] {
+    hipLaunchKernelGGL((k_apply4<false, 8>), dim3(gridC * 2), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out);
+  });
+  run("C apply alone (plan from the previous run) skip1", true, [&] {
+    hipLaunchKernelGGL((k_apply<true, false, 4>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out);
+  });
+  run("B G16 nt0 w4", true, [&] { hipLaunchKernelGGL((k_chan16<false, 4>), dim3(g16), dim3(512), 0, st, dT, dw, norm, R, nf, ch, d_out); });
+  run("B G16 nt1 w4", true, [&] { hipLaunchKernelGGL((k_chan16<true, 4>), dim3(g16), dim3(512), 0, st, dT, dw, norm, R, nf, ch, d_out); });
   return 0;
 }

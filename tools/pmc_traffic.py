@@ -83,7 +83,7 @@ def main():
     bw = run_pass(["WRITE_SIZE"], bench, os.path.join(scratch, "bench_write"))
     bh = run_pass(["TCC_HIT_sum", "TCC_MISS_sum"], bench, os.path.join(scratch, "bench_tcc"))
     kernels = {}
-    for label, needle in (("K1", K1), ("K2", "k_quantize"), ("D1", "k_imdct_chan"), ("D2", "k_overlap_add")):
+    for label, needle in (("K1", K1), ("K2", "k_quantize"), ("D1", "k_imdct_apply"), ("D2", "k_overlap_add")):
         f, n = pick(bf, needle, "FETCH_SIZE")
         w, _ = pick(bw, needle, "WRITE_SIZE")
         h, _ = pick(bh, needle, "TCC_HIT_sum")
