@@ -595,7 +595,9 @@ int flac_decode(const Span f, std::vector<float> &out, uint32_t &sample_rate, ui
   sample_rate = info_rate;
   channels = static_cast<uint16_t>(info_ch);
   // `(1 << (bits_per_sample - 1)) as f32`, audio.rs:72
-  const float scale = static_cast<float>(1ull << (info_bps - 1));
+  // `(1 << (info.bits_per_sample - 1)) as f32`, audio.rs:72, on an i32 literal: 32-bit streams divide by
+  // i32::MIN = -2147483648.0 (polarity inverted, quirk Q11, kept)
+  const float scale = info_bps == 32 ? -2147483648.0f : static_cast<float>(1ull << (info_bps - 1));
   out.clear();
   // STREAMINFO's sample count is a hint from the file, not a promise: reserve no more than the
   // remaining bytes could plausibly hold (the vector still grows if constant frames beat that)

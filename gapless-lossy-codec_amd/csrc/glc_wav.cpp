@@ -79,7 +79,10 @@ int glc_wav_load(const char *path, float **samples, uint64_t *n_samples, uint32_
   const uint64_t n = data_len / bps;
   float *out = static_cast<float *>(std::malloc((n ? n : 1) * sizeof(float)));
   if (!out) return GLC_ENOMEM;
-  const float max = static_cast<float>(1u << (bits - 1));  // (1 << (bits - 1)) as f32, audio.rs:55
+  // `(1 << (bits - 1)) as f32`, audio.rs:55: the literal is an i32, so for 32-bit samples the shift
+  // lands on the sign bit and the divisor is i32::MIN = -2147483648.0 - the reference inverts the
+  // polarity of 32-bit integer WAV files (quirk Q11, kept)
+  const float max = bits == 32 ? -2147483648.0f : static_cast<float>(1u << (bits - 1));
   for (uint64_t i = 0; i < n; ++i) {
     const uint8_t *p = data + i * bps;
     if (is_float) {

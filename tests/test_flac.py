@@ -260,7 +260,9 @@ def _pcm(n, ch, bps, seed, smooth=True):
 
 
 def _check_decode(data, pcm, ch, bps, rate):
-    want = (pcm.astype(np.int32).astype(np.float32)) / np.float32(1 << (bps - 1))
+    # audio.rs:72 `(1 << (bits_per_sample - 1)) as f32` on an i32 literal: i32::MIN at 32 bits (quirk Q11)
+    div = np.float32(-2147483648.0) if bps == 32 else np.float32(1 << (bps - 1))
+    want = (pcm.astype(np.int32).astype(np.float32)) / div
     y, r, c = glc_amd.decode_flac(data)
     assert (r, c) == (rate, ch) and np.array_equal(y, want)
     p2, r2, c2, b2 = F.decode_flac(data)

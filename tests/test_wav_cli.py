@@ -37,7 +37,10 @@ def test_load_wav_int_formats(tmp_path):
         _write_wav(p, 1, bits, 2, 44100, v.tobytes(), extensible=(bits == 32))
         x, sr, ch = glc_amd.load_wav(p)
         assert (sr, ch) == (44100, 2)
-        assert np.array_equal(x, v.astype(np.float32) / np.float32(2 ** (bits - 1)))   # audio.rs:54-58
+        # audio.rs:54-58: `(1 << (bits - 1)) as f32` on an i32 literal - at 32 bits that is i32::MIN, so the
+        # reference divides by -2147483648.0 and inverts the polarity of 32-bit files (quirk Q11)
+        div = np.float32(-2147483648.0) if bits == 32 else np.float32(2 ** (bits - 1))
+        assert np.array_equal(x, v.astype(np.float32) / div)
     v8 = rng.randint(0, 256, 999).astype(np.uint8)
     _write_wav(tmp_path / "u8.wav", 1, 8, 1, 8000, v8.tobytes())
     x, sr, ch = glc_amd.load_wav(tmp_path / "u8.wav")

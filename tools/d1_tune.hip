@@ -450,7 +450,7 @@ typedef unsigned u8v __attribute__((ext_vector_type(8)));
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
 constexpr unsigned kRecDwords = 16, kRecCap = 1024 + 4;
 
-__global__ __launch_bounds__(256) void k_plan(Rows rows, unsigned n_frames, unsigned ch, unsigned *plan_hdr, unsigned *plan_rec) {
+__global__ __launch_bounds__(256) void k_plan(Rows rows, unsigned n_frames, unsigned ch, unsigned *plan_hdr, unsigned *plan_rec, unsigned ahead = 2) {
   constexpr int G = 8;
   __shared__ __attribute__((aligned(16))) float s_c[kHopI * G];
   __shared__ unsigned s_mask[kHopI / 32];
@@ -515,14 +515,11 @@ __global__ __launch_bounds__(256) void k_plan(Rows rows, unsigned n_frames, unsi
     d1x4 *dst = reinterpret_cast<d1x4 *>(rec + static_cast<size_t>(j) * kRecDwords);
     dst[0] = lo;
     dst[1] = hi;
-    rec[static_cast<size_t>(j) * kRecDwords + 8] = static_cast<unsigned>(s_u[j + 2]) << 13;
+    rec[static_cast<size_t>(j) * kRecDwords + 8] = static_cast<unsigned>(s_u[j + ahead]) << 13;
   }
-  if (tid == 0) {
-    unsigned *h = plan_hdr + grp * 4;
-    h[0] = n_u;
-    h[1] = live;
-    h[2] = static_cast<unsigned>(s_u[0]) << 13;
-    h[3] = static_cast<unsigned>(s_u[1]) << 13;
+  if (tid < 8) {
+    unsigned *h = plan_hdr + grp * 8;
+    h[tid] = tid == 0 ? n_u : tid == 1 ? live : static_cast<unsigned>(s_u[tid - 2]) << 13;
   }
 }
 
@@ -562,7 +559,7 @@ void k_apply(const float *T, const float *win, float norm, const unsigned *plan_
   const unsigned fr0 = fgrp * G;
   if (fr0 >= n_frames) return;
   const unsigned grp = fgrp * ch + c;
-  const unsigned *hdr = plan_hdr + grp * 4;
+  const unsigned *hdr = plan_hdr + grp * 8;
   const unsigned n_u = __builtin_amdgcn_readfirstlane(hdr[0]);
   const unsigned live = __builtin_amdgcn_readfirstlane(hdr[1]);
   const unsigned k0 = __builtin_amdgcn_readfirstlane(hdr[2]), k1 = __builtin_amdgcn_readfirstlane(hdr[3]);
@@ -648,18 +645,19 @@ void k_apply(const float *T, const float *win, float norm, const unsigned *plan_
 // (scalar loads return out of order, so the only safe wait is lgkmcnt(0): fetching every other
 // entry doubles the slack of each wait), otherwise k_apply.
 // ------------------------------------------------------------------------------------------
-template <bool SKIP, int MINW>
+template <bool SKIP, int MINW, int R = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
 void k_apply_pair(const float *T, const float *win, float norm, const unsigned *plan_hdr, const unsigned *plan_rec,
-                  unsigned n_frames, unsigned ch, float *blocks) {
+                  unsigned n_frames, unsigned ch, float *blocks, unsigned long long *stamps = nullptr) {
   constexpr int G = 8;
+  const unsigned long long t_start = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const unsigned q_ = blockIdx.x >> 3;
   const unsigned c = q_ % ch;
   const unsigned fgrp = (q_ / ch) * 8u + (blockIdx.x & 7u);
   const unsigned fr0 = fgrp * G;
   if (fr0 >= n_frames) return;
   const unsigned grp = fgrp * ch + c;
-  const unsigned *hdr = plan_hdr + grp * 4;
+  const unsigned *hdr = plan_hdr + grp * 8;
   const unsigned n_u = __builtin_amdgcn_readfirstlane(hdr[0]);
   const unsigned live = __builtin_amdgcn_readfirstlane(hdr[1]);
   const unsigned k0 = __builtin_amdgcn_readfirstlane(hdr[2]), k1 = __builtin_amdgcn_readfirstlane(hdr[3]);
@@ -672,7 +670,7 @@ void k_apply_pair(const float *T, const float *win, float norm, const unsigned *
   for (int g = 0; g < G; ++g)
 #pragma unroll
     for (int h = 0; h < 4; ++h) acc[g][h] = d1x2{0.f, 0.f};
-  d1x4 t_lo[2], t_hi[2];
+  d1x4 t_lo[R], t_hi[R];
   u8v ca, cb, cc, cd;
   unsigned ka, kb, kc, kd;
   auto issue_tab = [&](d1x4 &lo, d1x4 &hi, unsigned koff) {
@@ -686,11 +684,16 @@ void k_apply_pair(const float *T, const float *win, float norm, const unsigned *
   };
   issue_tab(t_lo[0], t_hi[0], k0);
   issue_tab(t_lo[1], t_hi[1], k1);
+  if constexpr (R == 4) {
+    issue_tab(t_lo[2], t_hi[2], __builtin_amdgcn_readfirstlane(hdr[4]));
+    issue_tab(t_lo[R - 1], t_hi[R - 1], __builtin_amdgcn_readfirstlane(hdr[5]));
+  }
   asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dword %1, %4, 0x20\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_load_dword %3, %4, 0x60\n\ts_waitcnt lgkmcnt(0)"
                : "=&s"(ca), "=&s"(ka), "=&s"(cb), "=&s"(kb) : "s"(rec) : "memory");
 #define ENTRYP(S, CC_, KC_)                                                                                   \
   do {                                                                                                        \
-    asm volatile("s_waitcnt vmcnt(2)" : "+v"(t_lo[S]), "+v"(t_hi[S])::"memory");                                \
+    if (R == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(t_lo[S]), "+v"(t_hi[S])::"memory");                    \
+    else asm volatile("s_waitcnt vmcnt(6)" : "+v"(t_lo[S]), "+v"(t_hi[S])::"memory");                           \
     const u2v p0 = CC_.s01, p1 = CC_.s23, p2 = CC_.s45, p3 = CC_.s67;                                          \
     if (!SKIP || (p0.x | p0.y)) mac2rows_s(acc[0], acc[1], p0, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);  \
     if (!SKIP || (p1.x | p1.y)) mac2rows_s(acc[2], acc[3], p1, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);  \
@@ -714,8 +717,8 @@ void k_apply_pair(const float *T, const float *win, float norm, const unsigned *
     ENTRYP(1, cb, kb);
     WAIT2(cc, kc, cd, kd);
     FETCH2(ca, ka, cb, kb, j + 4);
-    ENTRYP(0, cc, kc);
-    ENTRYP(1, cd, kd);
+    ENTRYP(R == 2 ? 0 : 2, cc, kc);
+    ENTRYP(R == 2 ? 1 : R - 1, cd, kd);
   }
   if (j < n_u) {  // 1..3 entries left: (ca, cb) hold j, j+1
     WAIT2(ca, ka, cb, kb);
@@ -725,7 +728,7 @@ void k_apply_pair(const float *T, const float *win, float norm, const unsigned *
       ENTRYP(1, cb, kb);
       if (j + 2 < n_u) {
         WAIT2(cc, kc, cd, kd);
-        ENTRYP(0, cc, kc);
+        ENTRYP(R == 2 ? 0 : 2, cc, kc);
       }
     }
   }
@@ -733,7 +736,7 @@ void k_apply_pair(const float *T, const float *win, float norm, const unsigned *
 #undef FETCH2
 #undef WAIT2
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ca), "+s"(cb), "+s"(cc), "+s"(cd), "+s"(ka), "+s"(kb), "+s"(kc), "+s"(kd)::"memory");
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(t_lo[0]), "+v"(t_hi[0]), "+v"(t_lo[1]), "+v"(t_hi[1])::"memory");
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(t_lo[0]), "+v"(t_hi[0]), "+v"(t_lo[1]), "+v"(t_hi[1]), "+v"(t_lo[R - 2]), "+v"(t_hi[R - 2]), "+v"(t_lo[R - 1]), "+v"(t_hi[R - 1])::"memory");
   const d1x4 w0 = *reinterpret_cast<const d1x4 *>(win + col0), w1 = *reinterpret_cast<const d1x4 *>(win + col0 + 4);
 #pragma unroll
   for (int g = 0; g < G; ++g) {
@@ -746,6 +749,15 @@ void k_apply_pair(const float *T, const float *win, float norm, const unsigned *
     o1.z = mul_rn(mul_rn(acc[g][3].x, norm), w1.z); o1.w = mul_rn(mul_rn(acc[g][3].y, norm), w1.w);
     *reinterpret_cast<d1x4 *>(out) = o0;
     *reinterpret_cast<d1x4 *>(out + 4) = o1;
+  }
+  if (stamps && (threadIdx.x & 63) == 0) {  // per wave: {start, end (100 MHz), n_u, hardware id}
+    unsigned long long *o = stamps + (static_cast<size_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 4;
+    o[0] = t_start;
+    o[1] = __builtin_amdgcn_s_memrealtime();
+    o[2] = n_u;
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    o[3] = hw;
   }
 }
 
@@ -792,7 +804,7 @@ void k_apply4(const float *T, const float *win, float norm, const unsigned *plan
   const unsigned fr0 = fgrp * G;
   if (fr0 >= n_frames) return;
   const unsigned grp = fgrp * ch + c;
-  const unsigned *hdr = plan_hdr + grp * 4;
+  const unsigned *hdr = plan_hdr + grp * 8;
   const unsigned n_u = __builtin_amdgcn_readfirstlane(hdr[0]);
   const unsigned live = __builtin_amdgcn_readfirstlane(hdr[1]);
   const unsigned k0 = __builtin_amdgcn_readfirstlane(hdr[2]), k1 = __builtin_amdgcn_readfirstlane(hdr[3]);
@@ -1025,7 +1037,7 @@ int main(int argc, char **argv) {
   A(1, false, 2, 4);
   A(1, false, 3, 4);
   unsigned *d_hdr, *d_prec;
-  CHECK(hipMalloc(&d_hdr, size_t(g8) * 4 * 4));
+  CHECK(hipMalloc(&d_hdr, size_t(g8) * 8 * 4));
   CHECK(hipMalloc(&d_prec, size_t(g8) * kRecCap * kRecDwords * 4));
   const unsigned gridC = ((((nf + 7) / 8) + 7) / 8) * 8 * ch;
   run("C plan only", false, [&] { hipLaunchKernelGGL(k_plan, dim3(g8), dim3(256), 0, st, R, nf, ch, d_hdr, d_prec); });
@@ -1054,6 +1066,53 @@ int main(int argc, char **argv) {
   run("D apply4 alone skip0 w8", true, [&] {
     hipLaunchKernelGGL((k_apply4<false, 8>), dim3(gridC * 2), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out);
   });
+  run("C2 plan(ahead 4) + apply_pair R=4 skip1 w4", true, [&] {
+    hipLaunchKernelGGL(k_plan, dim3(g8), dim3(256), 0, st, R, nf, ch, d_hdr, d_prec, 4u);
+    hipLaunchKernelGGL((k_apply_pair<true, 4, 4>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, (unsigned long long *)nullptr);
+  });
+  run("C2 apply_pair R=4 alone", true, [&] {
+    hipLaunchKernelGGL((k_apply_pair<true, 4, 4>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, (unsigned long long *)nullptr);
+  });
+  hipLaunchKernelGGL(k_plan, dim3(g8), dim3(256), 0, st, R, nf, ch, d_hdr, d_prec, 2u);  // back to the R = 2 plan
+  {  // per-wave timeline of one apply_pair launch: when do waves end, and which are the last?
+    unsigned long long *d_st;
+    const size_t nw = size_t(gridC) * 4;
+    CHECK(hipMalloc(&d_st, nw * 32));
+    CHECK(hipMemset(d_st, 0, nw * 32));
+    for (int i = 0; i < 3; ++i)
+      hipLaunchKernelGGL((k_apply_pair<true, 4>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, d_st);
+    CHECK(hipStreamSynchronize(st));
+    std::vector<unsigned long long> hs(nw * 4);
+    CHECK(hipMemcpy(hs.data(), d_st, nw * 32, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (size_t w = 0; w < nw; ++w)
+      if (hs[w * 4 + 1]) t0 = std::min(t0, hs[w * 4]), t1 = std::max(t1, hs[w * 4 + 1]);
+    std::vector<double> ends, lens;
+    for (size_t w = 0; w < nw; ++w)
+      if (hs[w * 4 + 1]) ends.push_back((hs[w * 4 + 1] - t0) * 0.01), lens.push_back((hs[w * 4 + 1] - hs[w * 4]) * 0.01);
+    std::vector<double> se = ends;
+    std::sort(se.begin(), se.end());
+    double ml = 0;
+    for (double v : lens) ml += v;
+    printf("timeline: %zu waves, kernel span %.1f us; wave end times: p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f us; mean wave lifetime %.1f us\n",
+           ends.size(), (t1 - t0) * 0.01, se[se.size() / 10], se[se.size() / 2], se[se.size() * 9 / 10], se[se.size() * 99 / 100], se.back(), ml / lens.size());
+    // the 12 last waves
+    std::vector<size_t> idx;
+    for (size_t w = 0; w < nw; ++w)
+      if (hs[w * 4 + 1]) idx.push_back(w);
+    std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return hs[a * 4 + 1] > hs[b * 4 + 1]; });
+    for (int i = 0; i < 12 && i < (int)idx.size(); ++i) {
+      const size_t w = idx[i];
+      const unsigned hw = (unsigned)hs[w * 4 + 3];
+      printf("  last #%d: block %zu wave %zu n_u %llu start %.1f end %.1f us  hw_id 0x%08x (cu %u sh %u se %u simd %u)\n", i, w / 4, w % 4, hs[w * 4 + 2],
+             (hs[w * 4] - t0) * 0.01, (hs[w * 4 + 1] - t0) * 0.01, hw, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7, (hw >> 4) & 3);
+    }
+    // lifetime vs n_u
+    double s_lo = 0, s_hi = 0; int c_lo = 0, c_hi = 0;
+    for (size_t w = 0; w < nw; ++w)
+      if (hs[w * 4 + 1]) { if (hs[w * 4 + 2] < 200) s_lo += (hs[w * 4 + 1] - hs[w * 4]) * 0.01, ++c_lo; else s_hi += (hs[w * 4 + 1] - hs[w * 4]) * 0.01, ++c_hi; }
+    printf("  mean lifetime: n_u < 200: %.1f us (%d waves), n_u >= 200: %.1f us (%d waves)\n", c_lo ? s_lo / c_lo : 0, c_lo, c_hi ? s_hi / c_hi : 0, c_hi);
+  }
   run("C apply alone (plan from the previous run) skip1", true, [&] {
     hipLaunchKernelGGL((k_apply<true, false, 4>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out);
   });
