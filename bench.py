@@ -176,13 +176,14 @@ def main():
 
     # clocks: the device idles at a low DVFS state and needs some tens of milliseconds of load to
     # settle; a short spin-up (reported in config) keeps small --steps runs comparable to long ones
-    for _ in range(SPINUP_STEPS):
+    if dist_on:
+        step()
+        enc.synchronize()
+        gather_once()        # untimed: communicator / buffers of the collective exist before the clock starts
+    for _ in range(SPINUP_STEPS):   # after the collective's set-up, which lets the device clock down
         step()
     for _ in range(args.warmup):
         step()
-    if dist_on:
-        enc.synchronize()
-        gather_once()        # untimed: communicator / buffers of the collective exist before the clock starts
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

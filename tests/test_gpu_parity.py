@@ -910,3 +910,86 @@ def test_device_compaction_blob_equals_host_twin(torch_cuda):
         assert (i0.n_frames, i0.n_pairs, i0.n_raw_rows) == (0, 0, 0) and i0.bytes == glc_amd.compact_records(recs[:0], ch).size
         with pytest.raises(glc_amd.GlcError):
             enc.compact_device_records(d_rec.data_ptr(), plan.n_frames, ch, d_blob.data_ptr(), cap - 1)
+
+
+def _random_sparse_stream(rng, sr, ch, nf, max_nnz=160, raw_share=0.05):
+    """EncodedAudio with random sparse rows (a share of common indices per channel) and some raw
+    frames, built from fixed-size records - decode-side test material the encoder would never emit."""
+    rec = glc_amd.lib.glc_record_bytes(ch)
+    hdr = rec - 4096 * ch
+    M = nf * ch
+    nnz = rng.integers(0, max_nnz + 1, M)
+    common = [rng.permutation(1024) for _ in range(ch)]
+    buf = np.zeros((nf, rec), np.uint8)
+    pay = buf[:, hdr:].view(np.int16).reshape(nf, ch, 2048)
+    for c in range(ch):
+        for f in range(nf):
+            n = int(nnz[f * ch + c])
+            idx = common[c][:n] if rng.random() < 0.8 else rng.permutation(1024)[:n]
+            pay[f, c, idx] = rng.integers(1, 20000, n).astype(np.int16) * rng.choice(np.array([-1, 1], np.int16), n)
+    raw_frame = rng.random(nf) < raw_share
+    pay[raw_frame] = rng.integers(-32768, 32768, (int(raw_frame.sum()), ch, 2048)).astype(np.int16)
+    meta = buf[:, 8:8 + 8 * ch].view(np.uint32).reshape(nf, ch, 2)
+    meta[:, :, 0] = rng.uniform(1e-3, 1.0, (nf, ch)).astype(np.float32).view(np.uint32)
+    meta[:, :, 1] = (pay[:, :, :1024] != 0).sum(2)
+    buf[:, 0:4].view(np.uint32)[:, 0] = raw_frame
+    return glc_amd.EncodedAudio.from_records(sr, nf * 1024 * ch, ch, buf.reshape(-1))
+
+
+def _set_imdct_variant(ctx, v):
+    glc_amd.lib.glc_debug_set_imdct_variant.restype = C.c_int
+    glc_amd.lib.glc_debug_set_imdct_variant.argtypes = [C.c_void_p, C.c_int]
+    assert glc_amd.lib.glc_debug_set_imdct_variant(ctx._h, v) == 0
+
+
+@pytest.mark.parametrize("ch,nf", [(7, 2400), (300, 21), (1, 4100)])
+def test_d1_plan_batches_and_cross_check_kernels(torch_cuda, ch, nf):
+    """The shipped inverse transform (plan + apply) against the two cross-check forms of
+    include/glc_debug.h - one row per workgroup, and plan + apply without the scalar skip - bit for bit,
+    on streams whose (frame group, channel) units exceed one plan batch of 2048 units (7 ch x 300
+    groups, 300 ch x 3 groups with 6 groups per batch) and on a mono stream longer than one decode round."""
+    rng = np.random.default_rng(ch * 1000 + nf)
+    ea = _random_sparse_stream(rng, 48000, ch, nf)
+    dec = glc_amd.Decoder(ch, 48000)
+    outs = []
+    for v in (0, 1, 2):
+        _set_imdct_variant(dec, v)
+        d = torch_cuda.full(((nf + 1) * 1024 * ch,), float("nan"), dtype=torch_cuda.float32, device="cuda")
+        torch_cuda.cuda.synchronize()
+        dec.decode_device(ea, d.data_ptr(), d.numel())
+        dec.synchronize()
+        outs.append(d.cpu().numpy().view(np.uint32))
+    _set_imdct_variant(dec, 0)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    # and the same bits through the host API (rounds + D2H pipelining)
+    host = dec.decode(ea)
+    assert np.array_equal(bits(host), outs[0][512:512 + host.size])
+
+
+@pytest.mark.parametrize("ch", [1, 2, 4, 3])
+def test_raw_frames_in_a_later_round(torch_cuda, ch):
+    """Streams longer than one 4096-frame encode round with raw (noise) frames inside the SECOND round:
+    the quantiser takes the raw decision itself for 1 / 2 / 4 channels (the frame's rows sit in one
+    wave) and must window the right absolute frame; 3 channels go through k_decide_raw.  Records of a
+    window around the burst equal the oracle's, byte for byte."""
+    sr = 48000
+    nf = 4096 + 120
+    rng = np.random.default_rng(77 + ch)
+    t = np.arange(nf * 1024, dtype=np.float64)[:, None]
+    x = (np.sin(2 * np.pi * rng.uniform(100, 6000, (1, ch)) * t / sr) * 0.3).astype(np.float32)
+    lo, hi = (4096 + 30) * 1024, (4096 + 60) * 1024
+    x[lo:hi] = rng.standard_normal((hi - lo, ch)).astype(np.float32) * 0.3
+    x = x.reshape(-1)
+    plan = glc_amd.plan_encode(x.size, ch)
+    assert plan.n_frames == nf
+    recs, _ = device_encode(torch_cuda, x, sr, ch, want_coeffs=False)
+    rec = glc_amd.lib.glc_record_bytes(ch)
+    f0, f1 = 4096 + 20, 4096 + 70
+    t0, t1 = f0 * 1024 - 512, (f1 - 1) * 1024 - 512 + 2048
+    want, taps = O.encode_range_records(x[t0 * ch:t1 * ch], t0, t1 - t0, x.size, sr, ch, f0, f1, taps=True)
+    assert 10 < int(taps.is_raw.sum()) < f1 - f0
+    assert np.array_equal(recs[f0 * rec:f1 * rec], want)
+    # and the host API agrees with the device records
+    enc = glc_amd.Encoder(sr).encode(x, ch)
+    assert enc.to_bytes() == glc_amd.EncodedAudio.from_records(sr, x.size, ch, recs).to_bytes()
+    assert enc.info().n_raw_frames == int(split_records(recs, ch)[0].sum())
