@@ -404,6 +404,8 @@ def test_multi_gpu_host_tool(torch_cuda):
         p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300, env=env)
         assert p.returncode == 0, p.stdout + p.stderr
         assert "OK: every assembled stream is byte-identical" in p.stdout
+        if "--streams" not in args:   # the sharded decode leg runs in frames mode
+            assert "gathered PCM is bit-identical to the single-device decode" in p.stdout
 
 
 def test_cfg5_eight_channel_192k(torch_cuda):

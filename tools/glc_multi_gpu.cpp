@@ -11,6 +11,9 @@
 //       = a gather with per-rank sizes); the root copies the blobs to the host and assembles
 //       EncodedAudio (glc_frames_from_compact).  The .glc bytes are compared with a single-device
 //       glc_encode of the same stream.
+//   decode (frames mode)            the un-trimmed output has n_frames + 1 hops; device r decodes a contiguous
+//       hop range with glc_decode_range_device, the PCM pieces go to device 0 (same send/recv group)
+//       and are compared bit for bit with the single-device decode.
 //   --streams                       BASELINE config 4's other sharding: stream s <-> device s, every
 //       device encodes a whole stream of its own, same gather, one EncodedAudio per stream.
 //
@@ -272,6 +275,59 @@ int main(int argc, char **argv) {
     }
     glc_frames_free(single);
     glc_frames_free(result[s]);
+  }
+  // ---- decode, sharded the same way (frames mode): device r decodes a contiguous range of the
+  // n_frames + 1 output hops with glc_decode_range_device (the library recomputes the one halo frame
+  // the overlap-add carries, src/codec.rs:701-705), the PCM pieces go to device 0 in rank order -
+  // again one send/recv group - and must equal the single-device decode bit for bit.
+  if (!streams) {
+    glc_frames *whole = nullptr;
+    GLC_OK_(glc_encode(dev[0].ctx, pcm[0].data(), n_samples, kChannels, &whole), dev[0].ctx);
+    const uint64_t hops = plan.n_frames + 1, per_hop = uint64_t(GLC_HOP_SIZE) * kChannels;
+    std::vector<uint64_t> h0(world + 1, 0);
+    for (int r = 0; r < world; ++r) h0[r + 1] = h0[r] + hops / world + (uint64_t(r) < hops % world ? 1 : 0);
+    float *d_all = nullptr, *d_ref = nullptr;
+    HIP_OK(hipSetDevice(dev[0].id));
+    HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_all), hops * per_hop * sizeof(float)));
+    HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_ref), hops * per_hop * sizeof(float)));
+    std::vector<float *> d_part(world, nullptr);
+    for (int r = 0; r < world; ++r) {
+      const uint64_t n = (h0[r + 1] - h0[r]) * per_hop;
+      HIP_OK(hipSetDevice(dev[r].id));
+      d_part[r] = r == 0 ? d_all : nullptr;
+      if (r) HIP_OK(hipMalloc(reinterpret_cast<void **>(&d_part[r]), std::max<uint64_t>(n, 1) * sizeof(float)));
+      GLC_OK_(glc_decode_range_device(dev[r].ctx, whole, h0[r], h0[r + 1], d_part[r], n), dev[r].ctx);
+    }
+    NCCL_OK(ncclGroupStart());
+    for (int r = 1; r < world; ++r) {
+      const uint64_t n = (h0[r + 1] - h0[r]) * per_hop;
+      NCCL_OK(ncclSend(d_part[r], n, ncclFloat, 0, comm[r], dev[r].stream));
+      NCCL_OK(ncclRecv(d_all + h0[r] * per_hop, n, ncclFloat, r, comm[0], dev[0].stream));
+    }
+    NCCL_OK(ncclGroupEnd());
+    for (int r = 0; r < world; ++r) {
+      HIP_OK(hipSetDevice(dev[r].id));
+      HIP_OK(hipStreamSynchronize(dev[r].stream));
+    }
+    uint64_t start = 0, n_out = 0;
+    GLC_OK_(glc_decode_device(dev[0].ctx, whole, d_ref, hops * per_hop, &start, &n_out), dev[0].ctx);
+    GLC_OK_(glc_ctx_synchronize(dev[0].ctx), dev[0].ctx);
+    std::vector<float> a(hops * per_hop), b(hops * per_hop);
+    HIP_OK(hipSetDevice(dev[0].id));
+    HIP_OK(hipMemcpy(a.data(), d_all, a.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(b.data(), d_ref, b.size() * sizeof(float), hipMemcpyDeviceToHost));
+    const bool same = std::memcmp(a.data(), b.data(), a.size() * sizeof(float)) == 0;
+    std::printf("decode: %llu hops in %d shard(s), gathered PCM %s the single-device decode\n",
+                static_cast<unsigned long long>(hops), world, same ? "is bit-identical to" : "DIFFERS from");
+    if (!same) ++bad;
+    for (int r = 1; r < world; ++r) {
+      HIP_OK(hipSetDevice(dev[r].id));
+      HIP_OK(hipFree(d_part[r]));
+    }
+    HIP_OK(hipSetDevice(dev[0].id));
+    HIP_OK(hipFree(d_all));
+    HIP_OK(hipFree(d_ref));
+    glc_frames_free(whole);
   }
   const double msamples = double(n_samples) * n_streams / 1e6;
   std::printf("encode + compaction + gather + assembly: %.3f ms wall for %.1f Msamples (%.0f Msamples/s, first call: includes "
