@@ -139,6 +139,10 @@ int frames_from_compact(uint32_t sample_rate, uint64_t n_samples, uint16_t chann
       set_global_error("glc_frames_from_compact: blob shorter than its header");
       return GLC_EFORMAT;
     }
+    if (reinterpret_cast<uintptr_t>(blobs[b]) % 8 != 0) {  // the sections are read in place as u32 / f32 / u64
+      set_global_error("glc_frames_from_compact: blob must be 8-byte aligned");
+      return GLC_EINVAL;
+    }
     CompactHeader &h = hdrs[b];
     std::memcpy(&h, blobs[b], sizeof h);
     if (h.magic != kCompactMagic || h.channels != ch || h.n_frames > plan.n_frames) {

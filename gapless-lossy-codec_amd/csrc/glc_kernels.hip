@@ -372,41 +372,77 @@ __global__ __launch_bounds__(256) void k_imdct_plan(DecodeRows rows, unsigned ro
   // blockIdx = (frame group - fg_begin) * ch + channel: the batch covers whole frame groups
   const unsigned c = blockIdx.x % ch;
   const unsigned fr0 = (group_begin + blockIdx.x / ch) * G;
-  for (int i = tid; i < kHopI * G; i += 256) s_c[i] = 0.0f;
+  const int lane = tid & 63, w = tid >> 6;
+  // The kernel is a chain of latencies, so everything independent is issued together: the metadata
+  // of the 8 rows by 8 lanes at once (broadcast by shuffles afterwards) while the LDS is zeroed, then
+  // the first 256 pairs of ALL rows before any of them is scattered.
+  long long raw_l = -1;
+  unsigned long long p0_l = 0, rawlen_l = 0;
+  unsigned n_l = 0, valid_l = 0;
+  float scale_l = 0.0f;
+  if (lane < G && fr0 + lane < n_frames) {
+    const unsigned m = row_begin + (fr0 + lane) * ch + c;
+    raw_l = rows.row_raw[m];
+    rawlen_l = rows.row_raw_len[m];
+    p0_l = rows.row_begin[m];
+    n_l = min(rows.row_cnt[m], static_cast<unsigned>(kHopI));  // canonical lists hold <= 1024
+    scale_l = fmaxf(rows.row_scale[m], 1e-12f);                  // :653
+    valid_l = 1;
+  }
+  {
+    d1x4 *z = reinterpret_cast<d1x4 *>(s_c);
+    for (int i = tid; i < kHopI * G / 4; i += 256) z[i] = d1x4{0.f, 0.f, 0.f, 0.f};
+  }
   if (tid < kHopI / 32) s_mask[tid] = 0u;
-  __syncthreads();
-  unsigned live = 0;
+  unsigned live = 0, rawm = 0;
+  unsigned long long p0[G];
+  unsigned n[G];
+  float scale[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    const unsigned fr = fr0 + g;
-    if (fr >= n_frames) continue;
-    const unsigned r = fr * ch + c;
-    const unsigned m = row_begin + r;
-    const long long raw_off = rows.row_raw[m];
-    if (raw_off >= 0) {
-      // raw frame: read as if interleaved (Q1), /32767, no window (Q2) - src/codec.rs:629-640
+    const unsigned valid = __shfl(valid_l, g);
+    const long long raw_off = __shfl(raw_l, g);
+    p0[g] = __shfl(p0_l, g);
+    n[g] = __shfl(n_l, g);
+    scale[g] = __shfl(scale_l, g);
+    if (valid && raw_off >= 0) rawm |= 1u << g;
+    else if (valid) live |= 1u << g;
+    if (!(live & (1u << g))) n[g] = 0;
+  }
+  unsigned pr[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) pr[g] = static_cast<unsigned>(tid) < n[g] ? rows.pairs[p0[g] + tid] : 0xFFFFu;
+  __syncthreads();  // LDS zeroed
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const unsigned idx = pr[g] & 0xFFFFu;
+    if (idx < static_cast<unsigned>(kHopI)) {  // 0xFFFF = no pair for this thread (also what a reader must ignore, :660)
+      const short q = static_cast<short>(pr[g] >> 16);
+      s_c[idx * G + g] = mul_rn(static_cast<float>(q) / 32768.0f, scale[g]);  // :663
+      atomicOr(&s_mask[idx >> 5], 1u << (idx & 31));
+    }
+    for (unsigned j = tid + 256; j < n[g]; j += 256) {  // lists longer than 256 entries
+      const unsigned p = rows.pairs[p0[g] + j];
+      const unsigned k = p & 0xFFFFu;
+      if (k < static_cast<unsigned>(kHopI)) {
+        s_c[k * G + g] = mul_rn(static_cast<float>(static_cast<short>(p >> 16)) / 32768.0f, scale[g]);
+        atomicOr(&s_mask[k >> 5], 1u << (k & 31));
+      }
+    }
+  }
+  if (rawm) {  // raw frames: read as if interleaved (Q1), /32767, no window (Q2) - src/codec.rs:629-640
+#pragma unroll 1
+    for (int g = 0; g < G; ++g) {
+      if (!(rawm & (1u << g))) continue;
+      const unsigned r = (fr0 + g) * ch + c;
       float *out = blocks + static_cast<size_t>(r) * kFrameI;
-      const unsigned long long raw_len = rows.row_raw_len[m];
-      const short *raw = rows.raw_pool + raw_off;
+      const unsigned long long raw_len = __shfl(rawlen_l, g);
+      const short *raw = rows.raw_pool + __shfl(raw_l, g);
       for (int i = tid; i < kFrameI; i += 256) {
         const unsigned long long si = static_cast<unsigned long long>(i) * ch + c;
         float v = 0.0f;
         if (si < raw_len) v = static_cast<float>(raw[si]) / 32767.0f;
         out[i] = v;
-      }
-      continue;
-    }
-    live |= 1u << g;
-    const unsigned long long p0 = rows.row_begin[m];
-    const unsigned n = min(rows.row_cnt[m], static_cast<unsigned>(kHopI));  // canonical lists hold <= 1024
-    const float scale = fmaxf(rows.row_scale[m], 1e-12f);                  // :653
-    for (unsigned j = tid; j < n; j += 256) {
-      const unsigned pr = rows.pairs[p0 + j];
-      const unsigned idx = pr & 0xFFFFu;
-      const short q = static_cast<short>(pr >> 16);
-      if (idx < static_cast<unsigned>(kHopI)) {
-        s_c[idx * G + g] = mul_rn(static_cast<float>(q) / 32768.0f, scale);  // :663
-        atomicOr(&s_mask[idx >> 5], 1u << (idx & 31));
       }
     }
   }
@@ -415,7 +451,6 @@ __global__ __launch_bounds__(256) void k_imdct_plan(DecodeRows rows, unsigned ro
   const unsigned nib = (s_mask[tid >> 3] >> ((tid & 7) * 4)) & 0xFu;
   const unsigned cnt = __popc(nib);
   unsigned incl = cnt;
-  const int lane = tid & 63, w = tid >> 6;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
     const unsigned v = __shfl_up(incl, off);

@@ -167,8 +167,8 @@ int glc_compact_device_records(glc_ctx *ctx, const void *d_records, uint64_t n_f
 int glc_compact_records(const void *records, uint64_t n_frames, uint16_t channels, void *blob, uint64_t cap,
                         glc_compact_info *info);
 /* Host assembly of EncodedAudio (header + gapless info as src/codec.rs:543-564) from `n_blobs`
- * host-resident blobs that together cover the stream's frames in order.  Every count in a blob is
- * validated against its size; GLC_EFORMAT on inconsistency. */
+ * host-resident blobs (each 8-byte aligned) that together cover the stream's frames in order.  Every
+ * count in a blob is validated against its size; GLC_EFORMAT on inconsistency. */
 int glc_frames_from_compact(uint32_t sample_rate, uint64_t n_samples, uint16_t channels,
                             const void *const *blobs, const uint64_t *blob_bytes, uint32_t n_blobs,
                             glc_frames **out);
