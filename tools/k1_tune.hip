@@ -147,6 +147,11 @@ int main(int argc, char **argv) {
       Variant{"SHIPPED sched 64x128 256thr (513..4095 rows)", k1::launch_sched<64, 128, 16, 4>},
       Variant{"SHIPPED hipcc-scheduled 32x64 t4x4 (<= 512 rows)", k1::launch<32, 64, 32, 4, 4, 4, 2>},
       // tuning variants (tools/k1_variants.hpp)
+      Variant{"dma segment loader, no stagger (k1x copy of the shipped kernel)", k1x::launch_dma<4, 0, 128, 2, 0>},
+      Variant{"dma segment loader, odd workgroups start 16 x 64 cycles late", k1x::launch_dma<4, 0, 128, 2, 16>},
+      Variant{"dma segment loader, odd workgroups start 32 x 64 cycles late", k1x::launch_dma<4, 0, 128, 2, 32>},
+      Variant{"dma segment loader, odd workgroups start 64 x 64 cycles late", k1x::launch_dma<4, 0, 128, 2, 64>},
+      Variant{"dma segment loader, odd workgroups start 100 x 64 cycles late", k1x::launch_dma<4, 0, 128, 2, 100>},
       Variant{"sched pk 128x128 bk16 t4x8 w4 512thr (shipped, M < 16384)", k1x::launch_sched<128, 128, 16, 4, 0, 4>},
       Variant{"sched pk 128x128 bk16 t8x8 w3 256thr (shipped, M >= 16384)", k1x::launch_sched<128, 128, 16, 3, 0, 8>},
       Variant{"sched pk 128x128 bk16 t4x8 w4 512thr + window in LDS", k1x::launch_sched<128, 128, 16, 4, 0, 4, false, 2, true>},

@@ -641,7 +641,7 @@ inline hipError_t launch_sched(const DeviceTables &t, const PcmView &pcm, uint64
 // `s_waitcnt vmcnt(1)` per stage waits for the PCM loads and the table DMA of the NEXT stage while
 // leaving the DMA of the stage after it in flight.  Same arithmetic, same order.
 // ------------------------------------------------------------------------------------------
-template <int MINW, int ABL = 0, int BM = 128, int CH = 0>
+template <int MINW, int ABL = 0, int BM = 128, int CH = 0, int STAGGER = 0>
 __global__ __launch_bounds__(4 * BM) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
 void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigned M, float *__restrict__ coef) {
   // CH = 0: one PCM dword per (row, i) and lane - any channel count.  CH = 1 / 2 / 4 / 8 (the
@@ -672,6 +672,11 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
   const int tx = tid % 16, ty = tid / 16;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
+  // STAGGER (tuning): every other workgroup of an XCD starts STAGGER x 64 cycles late, so that the two
+  // workgroups sharing a CU do not hit their per-stage barriers at the same moment
+  if constexpr (STAGGER > 0) {
+    if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_sleep(STAGGER);
+  }
 
   if constexpr (kWinLds)
     for (int i = tid; i < kFrameI; i += kThreads) Ws[i] = tb.window[i];
@@ -864,13 +869,13 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
   }
 }
 
-template <int MINW, int ABL = 0, int BM = 128, int CH = 0>
+template <int MINW, int ABL = 0, int BM = 128, int CH = 0, int STAGGER = 0>
 inline hipError_t launch_dma(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M,
                              float *coef, hipStream_t s) {
   if (M == 0) return hipSuccess;
   if (CH != 0 && pcm.ch != static_cast<uint32_t>(CH)) return hipErrorInvalidValue;
   const unsigned m_tiles = (M + BM - 1) / BM;
-  hipLaunchKernelGGL((k_mdct_fwd_dma<MINW, ABL, BM, CH>), dim3(m_tiles * 8), dim3(4 * BM), 0, s, t, pcm,
+  hipLaunchKernelGGL((k_mdct_fwd_dma<MINW, ABL, BM, CH, STAGGER>), dim3(m_tiles * 8), dim3(4 * BM), 0, s, t, pcm,
                      static_cast<long long>(frame_begin), M, coef);
   return hipGetLastError();
 }
