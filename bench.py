@@ -308,9 +308,9 @@ def main():
                          "h2d_bytes": int(pcm_bytes),
                          "pcie_gen5_x16_GBs": 63.0,
                          "h2d_floor_ms_at_pcie_peak": round(pcm_bytes / 63.0e9 * 1e3, 3),
-                         "note": "host f32 PCM (pageable, caller-owned) -> H2D in sub-rounds overlapped with the "
-                                 "kernels -> device-side compaction -> one D2H of the compact blob through pinned "
-                                 "memory -> EncodedAudio; best of 5"}
+                         "note": "host f32 PCM (pageable, caller-owned) -> H2D in two half-batch rounds, the second under "
+                                 "the first round's kernels -> device-side compaction -> D2H of the payload straight "
+                                 "into the EncodedAudio pools; best of 5"}
 
     # ---- decode of the same batch, device-resident (sparse rows resident -> interleaved PCM in
     # HBM): D1 sparse IMDCT + window, D2 overlap-add.  Beside the headline, never `value`. ---------
