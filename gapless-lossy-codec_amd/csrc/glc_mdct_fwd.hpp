@@ -517,9 +517,9 @@ inline hipError_t launch_sched(const DeviceTables &t, const PcmView &pcm, uint64
 // The table tile of stage s+2 is copied global -> LDS by `global_load_lds_dwordx4` while stages s
 // and s+1 compute: two stages of latency budget, no VGPRs and no ds_write for the table.  The PCM
 // tile (needs the window multiply) goes through registers one stage ahead, the window itself sits
-// in LDS.  All vector-memory operations of the loop are inline asm so that ONE counted
-// `s_waitcnt vmcnt(1)` per stage waits for the PCM loads and the table DMA of the NEXT stage while
-// leaving the DMA of the stage after it in flight.  Same arithmetic, same order.
+// in LDS.  The PCM loads of the loop are inline asm (hipcc must not move their first use); one
+// `s_waitcnt vmcnt(0)` per stage, in the middle of the stage, retires loads that are a stage old.
+// Same arithmetic, same order.
 // ------------------------------------------------------------------------------------------
 template <int MINW, int CH = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
@@ -629,11 +629,11 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
       As[slot][ii * BM + a_r] = mul_rn(a_raw[j], Ws[i0 + ii]);  // block[i] = slice[i]*window[i], :480
     }
   };
-  auto wait_all_but_newest_dma = [&]() {
+  auto wait_staged = [&]() {  // everything this wave has in flight: PCM registers + table DMA of the next stage
     if constexpr (kSeg)
-      asm volatile("s_waitcnt vmcnt(1)" : "+v"(a_seg)::"memory");
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(a_seg)::"memory");
     else
-      asm volatile("s_waitcnt vmcnt(1)" : "+v"(a_raw[0]), "+v"(a_raw[1]), "+v"(a_raw[2]), "+v"(a_raw[3])::"memory");
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(a_raw[0]), "+v"(a_raw[1]), "+v"(a_raw[2]), "+v"(a_raw[3])::"memory");
   };
 
   f32x2 acc[TM][4];
@@ -658,29 +658,45 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
   const unsigned a_lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(&As[0][ty * 4]));
   const unsigned b_lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(&Bs[0][tx * 4]));
 
+  // Stage hand-off in the MIDDLE of a stage (round 2): the next stage's tiles are published by a
+  // barrier after the first 8 i-steps, so the stage's last i-step prefetches the first operands of
+  // the next stage and no wave starts a stage with an exposed LDS round trip.  The table DMA and the
+  // PCM loads of stage s+2 are issued right after that barrier - every wave has then left stage s-1,
+  // whose slot the DMA overwrites - and have 1.5 stages to land, so the mid-stage wait is a plain
+  // vmcnt(0) on loads that are a whole stage old.  Slot use: stage s reads slot s % 3; As[(s+1) % 3]
+  // is written before the barrier of stage s (last read in stage s-2), Bs[(s+2) % 3] after it.
+  // Measured against the end-of-stage hand-off with a counted vmcnt(1) (round 1, kept as
+  // k1x::k_mdct_fwd_dma in tools/k1_variants.hpp): the same time within run-to-run noise (0.58 ms,
+  // profiles/r02_k1_tune_mid_stage.txt) - the hand-off is not where the idle issue slots come from -
+  // so the simpler protocol (one plain wait on stage-old loads, no exposed fetch) is the one shipped.
+  Operands X, Y;
+  lds_fetch4<BM, BN>(X, a_lds0, b_lds0, 0);
+  lds_wait4(X);
 #pragma unroll 1
   for (int s = 0; s < kStages; ++s) {
-    const int slot = s % 3;
-    // in flight on entry: PCM loads of stage s+1 (regs) and table DMA of stage s+1 (slot (s+1)%3)
-    issue_b(((s + 2) & (kStages - 1)) * BK, (s + 2) % 3);  // slot of stage s-1: free since the barrier
+    const int slot = s % 3, nslot = (s + 1) % 3;
     const unsigned a_addr = a_lds0 + slot * (BK * BM * 4);
     const unsigned b_addr = b_lds0 + slot * (BK * BN * 4);
-    Operands X, Y;
-    lds_fetch4<BM, BN>(X, a_addr, b_addr, 0);
-    lds_wait4(X);
+    const unsigned a_next = a_lds0 + nslot * (BK * BM * 4);
+    const unsigned b_next = b_lds0 + nslot * (BK * BN * 4);
 #pragma unroll
-    for (int ii = 0; ii < BK; ii += 2) {
+    for (int ii = 0; ii < BK / 2; ii += 2) {
       step4<BM, BN, true>(acc, X, Y, a_addr, b_addr, ii + 1);
-      if (ii + 2 < BK) step4<BM, BN, true>(acc, Y, X, a_addr, b_addr, ii + 2);
-      else step4<BM, BN, false>(acc, Y, X, a_addr, b_addr, 0);
+      step4<BM, BN, true>(acc, Y, X, a_addr, b_addr, ii + 2);
     }
-    // everything but the youngest vector-memory op (the DMA of stage s+2) has landed: the PCM
-    // registers of stage s+1 and, older still, the table DMA of stage s+1
-    wait_all_but_newest_dma();
-    store_a(((s + 1) & (kStages - 1)) * BK, (s + 1) % 3);
-    issue_a(((s + 2) & (kStages - 1)) * BK);
+    // stage s+1: its PCM registers and table DMA (both issued in the middle of stage s-1) have landed
+    wait_staged();
+    store_a(((s + 1) & (kStages - 1)) * BK, nslot);
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's ds_writes of stage s+1 have landed
     __builtin_amdgcn_s_barrier();
+    issue_b(((s + 2) & (kStages - 1)) * BK, (s + 2) % 3);  // the slot of stage s-1: every wave has left it
+    issue_a(((s + 2) & (kStages - 1)) * BK);
+#pragma unroll
+    for (int ii = BK / 2; ii < BK; ii += 2) {
+      step4<BM, BN, true>(acc, X, Y, a_addr, b_addr, ii + 1);
+      if (ii + 2 < BK) step4<BM, BN, true>(acc, Y, X, a_addr, b_addr, ii + 2);
+      else step4<BM, BN, true>(acc, Y, X, a_next, b_next, 0);  // the first operands of stage s+1
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the wrap-around prefetches
 

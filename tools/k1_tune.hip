@@ -141,13 +141,15 @@ int main(int argc, char **argv) {
 
   // hand-scheduled kernels (shipped shapes first), their ablations, then hipcc-scheduled shapes
   std::vector<Variant> vs = {
+      // (the first line of a run is measured on a cold device: it is repeated further down)
+      Variant{"warm-up: SHIPPED dma, segment loader", k1::launch_dma<4, 2>},
       // the three kernels libglc_hip.so ships (csrc/glc_mdct_fwd.hpp)
       Variant{"SHIPPED dma 128x128 512thr, per-row PCM loader (>= 4096 rows, other channel counts)", k1::launch_dma<4>},
       Variant{"SHIPPED dma 128x128 512thr, dwordx4 segment loader (>= 4096 rows, stereo)", k1::launch_dma<4, 2>},
       Variant{"SHIPPED sched 64x128 256thr (513..4095 rows)", k1::launch_sched<64, 128, 16, 4>},
       Variant{"SHIPPED hipcc-scheduled 32x64 t4x4 (<= 512 rows)", k1::launch<32, 64, 32, 4, 4, 4, 2>},
       // tuning variants (tools/k1_variants.hpp)
-      Variant{"dma segment loader, no stagger (k1x copy of the shipped kernel)", k1x::launch_dma<4, 0, 128, 2, 0>},
+      Variant{"dma segment loader, round-1 protocol: end-of-stage hand-off, counted vmcnt(1)", k1x::launch_dma<4, 0, 128, 2, 0>},
       Variant{"dma segment loader, odd workgroups start 16 x 64 cycles late", k1x::launch_dma<4, 0, 128, 2, 16>},
       Variant{"dma segment loader, odd workgroups start 32 x 64 cycles late", k1x::launch_dma<4, 0, 128, 2, 32>},
       Variant{"dma segment loader, odd workgroups start 64 x 64 cycles late", k1x::launch_dma<4, 0, 128, 2, 64>},
