@@ -357,7 +357,7 @@ typedef float d1x4 __attribute__((ext_vector_type(4)));
 typedef unsigned d1u8 __attribute__((ext_vector_type(8)));
 typedef unsigned d1u2 __attribute__((ext_vector_type(2)));
 constexpr unsigned kPlanRecDwords = 16;       // 64-byte records
-constexpr unsigned kPlanHdrDwords = 8;        // {n_u, live rows, table offsets of the first <= 4 entries, pad}
+constexpr unsigned kPlanHdrDwords = 8;        // {n_u, live rows, table offsets of the first <= 4 entries, dense flag, pad}
 constexpr unsigned kPlanRecCap = kHopI + 8;   // per group: the union holds <= 1024 entries; the apply loop reads a few past
 
 __global__ __launch_bounds__(256) void k_imdct_plan(DecodeRows rows, unsigned row_begin, unsigned n_frames, unsigned ch,
@@ -484,7 +484,12 @@ __global__ __launch_bounds__(256) void k_imdct_plan(DecodeRows rows, unsigned ro
   }
   if (tid < 8) {
     unsigned *h = plan_hdr + static_cast<size_t>(blockIdx.x) * kPlanHdrDwords;
-    h[tid] = tid == 0 ? n_u : tid == 1 ? live : tid < 2 + ahead ? static_cast<unsigned>(s_u[tid - 2]) << 13 : 0u;
+    // h[6]: 1 when the rows share most of their indices (union <= 2x the mean list), see k_imdct_apply
+    unsigned total = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) total += n[g];
+    const unsigned dense = n_u * G <= 2u * total ? 1u : 0u;
+    h[tid] = tid == 0 ? n_u : tid == 1 ? live : tid < 2 + ahead ? static_cast<unsigned>(s_u[tid - 2]) << 13 : tid == 6 ? dense : 0u;
   }
 }
 
@@ -515,7 +520,7 @@ __device__ __forceinline__ void d1_mac2rows_s(d1x2 (&c0)[4], d1x2 (&c1)[4], d1u2
 
 // Two table rows per wave in registers: the one being applied and the next, in flight (four were
 // measured and bought nothing: tools/d1_tune.hip, profiles/r02_d1_*).
-template <bool SKIP>
+template <bool SKIP, bool PRIO = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_imdct_apply(DeviceTables tb, const unsigned *__restrict__ plan_hdr, const unsigned *__restrict__ plan_rec,
                    unsigned n_frames, unsigned ch, unsigned group_begin, unsigned n_groups, float *__restrict__ blocks) {
@@ -534,12 +539,21 @@ void k_imdct_apply(DeviceTables tb, const unsigned *__restrict__ plan_hdr, const
   const unsigned n_u = __builtin_amdgcn_readfirstlane(hdr[0]);
   const unsigned live = __builtin_amdgcn_readfirstlane(hdr[1]);
   if (!live) return;
-  // A wave's run time is its union length; the kernel ends with its longest wave.  Waves with long
-  // unions (the broadband frames at a stream's edges double it) take issue priority over the three
-  // waves they share a SIMD with, so that the critical path runs at full speed instead of on leftovers.
-  if (n_u >= 256) __builtin_amdgcn_s_setprio(3);
-  else if (n_u >= 208) __builtin_amdgcn_s_setprio(2);
-  else if (n_u >= 176) __builtin_amdgcn_s_setprio(1);
+  // The four waves of a SIMD are arbitrated oldest-first, so left alone they finish one after the
+  // other (at 25 / 50 / 75 / 100 % of the kernel) and the last one runs by itself, with nobody to
+  // fill its scalar and wait slots.  Each wave therefore lowers its own issue priority as it gets
+  // through its union (3 in the first quarter ... 0 in the last): whoever is furthest behind goes
+  // first, the waves of a SIMD progress together and keep covering each other's stalls to the end
+  // (config 2: 120 -> 112 us; fully shared indices: 102 -> 90 us).  Only for units whose rows share
+  // most indices: when entries are mostly one row pair long the steps are too short for this to pay
+  // (0 % shared: 224 -> 246 us with it), so the plan kernel flags the dense units.
+  const unsigned dense_unit = PRIO ? __builtin_amdgcn_readfirstlane(hdr[6]) : 0u;
+  const unsigned q1 = n_u >> 2, q2 = n_u >> 1, q3 = q1 + q2;
+  unsigned prio_next = dense_unit ? q1 : 0xFFFFFFFFu, prio_level = 0;  // scalar state: one compare per 4 entries
+  // units that are not dense keep the top priority throughout: they are the long ones (the broadband
+  // frames at a stream's edges double their union), and in a launch where every unit is like that
+  // equal priorities change nothing
+  if (PRIO) __builtin_amdgcn_s_setprio(3);
   const unsigned *rec = plan_rec + static_cast<size_t>(local) * kPlanRecCap * kPlanRecDwords;
   const unsigned col0 = static_cast<unsigned>(threadIdx.x) * 8u;  // 8 consecutive outputs per lane
   const unsigned lane_off = col0 * 4u;
@@ -595,6 +609,13 @@ void k_imdct_apply(DeviceTables tb, const unsigned *__restrict__ plan_hdr, const
   unsigned j = 0;
 #pragma unroll 1
   for (; j + 4 <= n_u; j += 4) {
+    if (j >= prio_next) {  // crossed a quarter of the union: three times per wave
+      ++prio_level;
+      if (prio_level == 1) __builtin_amdgcn_s_setprio(2);
+      else if (prio_level == 2) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+      prio_next = prio_level == 1 ? q2 : prio_level == 2 ? q3 : 0xFFFFFFFFu;
+    }
     GLC_D1_WAIT2(ca, ka, cb, kb);
     GLC_D1_FETCH2(cc, kc, cd, kd, j + 2);
     GLC_D1_ENTRY(0, ca, ka);
@@ -920,6 +941,8 @@ hipError_t launch_imdct_rows(const DeviceTables &t, const DecodeRows &rows, uint
     hipLaunchKernelGGL(k_imdct_plan, dim3(n_fg * ch), dim3(256), 0, s, rows, row_begin, n_frames, ch, fg0, 2u, hdr, rec, blocks);
     if (variant == 2)
       hipLaunchKernelGGL(k_imdct_apply<false>, grid, dim3(256), 0, s, t, hdr, rec, n_frames, ch, fg0, n_fg, blocks);
+    else if (variant == 3)
+      hipLaunchKernelGGL((k_imdct_apply<true, false>), grid, dim3(256), 0, s, t, hdr, rec, n_frames, ch, fg0, n_fg, blocks);
     else
       hipLaunchKernelGGL(k_imdct_apply<true>, grid, dim3(256), 0, s, t, hdr, rec, n_frames, ch, fg0, n_fg, blocks);
   }

@@ -51,7 +51,7 @@ for r in range(rounds):
     buf[:, 0:4].view(np.uint32)[:, 0] = raw_frame
     ea = glc_amd.EncodedAudio.from_records(48000, nf * 1024 * ch, ch, buf.reshape(-1))
     outs = []
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3):
         assert glc_amd.lib.glc_debug_set_imdct_variant(dec._h, variant) == 0
         d = torch.full(((nf + 1) * 1024 * ch,), float("nan"), dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()
@@ -61,7 +61,7 @@ for r in range(rounds):
     if not all(np.array_equal(outs[0], o) for o in outs[1:]):
         bad += 1
         print(f"round {r} (ch {ch}, {nf} frames): outputs differ in "
-              f"{[int((outs[0] != o).sum()) for o in outs[1:]]} samples (one-row / no-skip)", flush=True)
+              f"{[int((outs[0] != o).sum()) for o in outs[1:]]} samples (one-row / no-skip / no-priority)", flush=True)
     if r % 10 == 9 or r == rounds - 1:
         print(f"decode soak round {r + 1}: {bad} differing streams so far ({time.time() - t0:.0f} s)", flush=True)
 glc_amd.lib.glc_debug_set_imdct_variant(dec._h, 0)
