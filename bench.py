@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_PEAK_TFLOPS = 157.3           # f32 vector peak with FMA = 2 flop (MI355X_MICROARCH.md)
 F32_UNFUSED_TFLOPS = F32_PEAK_TFLOPS / 2.0  # separately rounded mul + add: one flop per issue slot
 K1_KERNEL = "glc::k1::k_mdct_fwd_dma<4, 2>"   # name in rocprofv3's kernel trace
-D1_KERNEL = "glc::k_imdct_plan + glc::k_imdct_apply<true>"
+D1_KERNEL = "glc::k_imdct_plan + glc::k_imdct_apply<true, true>"
 
 
 def make_shard_pcm(np, rank, world):
