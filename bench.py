@@ -66,6 +66,7 @@ def chord(np, t0, t_count):
 
 
 SPINUP_STEPS = 150  # untimed, before the --warmup steps
+DECODE_SPINUP_CALLS = 400  # untimed decode calls before the decode leg is timed
 
 
 def launch_ranks(args):
@@ -79,7 +80,8 @@ def launch_ranks(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
-           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--spinup", str(args.spinup)]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
@@ -101,6 +103,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spinup", type=int, default=SPINUP_STEPS,
+                    help="untimed steps before --warmup that bring the device clock up after the idle set-up phase")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return launch_ranks(args)
@@ -180,7 +184,7 @@ def main():
         step()
         enc.synchronize()
         gather_once()        # untimed: communicator / buffers of the collective exist before the clock starts
-    for _ in range(SPINUP_STEPS):   # after the collective's set-up, which lets the device clock down
+    for _ in range(args.spinup):   # after the collective's set-up, which lets the device clock down
         step()
     for _ in range(args.warmup):
         step()
@@ -264,7 +268,7 @@ def main():
         for sr2 in (44100, 96000):
             e2 = glc_amd.Encoder(sr2, device=local_rank)
             reps = max(10, min(args.steps, 50))
-            for _ in range(SPINUP_STEPS):  # the device clocked down while the host built this rate's tables
+            for _ in range(args.spinup):  # the device clocked down while the host built this rate's tables
                 e2.encode_range_device(d_pcm.data_ptr(), me.t0, me.t_count, n_samples, CH, me.frame_begin,
                                        me.frame_end, d_rec.data_ptr())
             e2.timer_begin()
@@ -321,12 +325,14 @@ def main():
         d_all = torch.empty((FRAMES_PER_GPU + 1) * HOP * CH, dtype=torch.float32, device="cuda")
         d_blk = torch.empty((FRAMES_PER_GPU * CH, 2048), dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()
-        reps = max(5, min(args.steps, 20))
+        reps = max(20, min(args.steps, 100))
         t_u0 = time.perf_counter()
         dec.decode_device(ea_d, d_all.data_ptr(), d_all.numel())   # first call: row prep + upload
         dec.synchronize()
         first_ms = (time.perf_counter() - t_u0) * 1e3
-        for _ in range(30):
+        # the device clocked down while the host built the EncodedAudio: bring it back up first (the
+        # same reason as SPINUP_STEPS for the encode; 400 calls = 45 ms)
+        for _ in range(DECODE_SPINUP_CALLS):
             dec.decode_device(ea_d, d_all.data_ptr(), d_all.numel())
         dec.synchronize()
         t_d0 = time.perf_counter()
@@ -334,7 +340,8 @@ def main():
             dec.decode_device(ea_d, d_all.data_ptr(), d_all.numel())
         dec.synchronize()
         d_ms = (time.perf_counter() - t_d0) * 1e3 / reps
-        dec.imdct_device(ea_d, 0, FRAMES_PER_GPU, d_blk.data_ptr())
+        for _ in range(20):
+            dec.imdct_device(ea_d, 0, FRAMES_PER_GPU, d_blk.data_ptr())
         dec.timer_begin()
         for _ in range(reps):
             dec.imdct_device(ea_d, 0, FRAMES_PER_GPU, d_blk.data_ptr())
@@ -399,7 +406,7 @@ def main():
                        "samples_per_step": samples_per_step,
                        "sharding": f"frame-range x{world}" + (", one gather of the compact blobs at the end "
                                                                "(inside the timed region)" if dist_on else ""),
-                       "spinup_steps": SPINUP_STEPS},
+                       "spinup_steps": args.spinup, "decode_spinup_calls": DECODE_SPINUP_CALLS},
             "roofline": {"bound": "valu", "kernel": K1_KERNEL, "achieved": round(k1_tflops, 3),
                          "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(k1_tflops / F32_PEAK_TFLOPS, 4),

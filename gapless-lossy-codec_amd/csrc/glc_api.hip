@@ -883,7 +883,7 @@ int glc_imdct_device(glc_ctx *ctx, const glc_frames *in, uint64_t frame_begin, u
 }
 
 int glc_debug_set_imdct_variant(glc_ctx *ctx, int variant) {
-  if (!ctx || variant < 0 || variant > 3) return fail(ctx, GLC_EINVAL, "glc_debug_set_imdct_variant: variant must be 0..3");
+  if (!ctx || variant < 0 || variant > 4) return fail(ctx, GLC_EINVAL, "glc_debug_set_imdct_variant: variant must be 0..4");
   ctx->d1_variant = variant;
   return GLC_OK;
 }

@@ -65,7 +65,7 @@ struct DecodeRows {
 };
 // variant (include/glc_debug.h): 0 = shipped (k_imdct_plan + k_imdct_apply, absent row pairs skipped
 // by scalar branches); 1 = one row per workgroup (the cross-check kernel); 2 = plan + apply without
-// the skip; 3 = without the issue-priority schedule.  All but 1 need a workspace `plan` of imdct_plan_bytes(plan_groups) bytes,
+// the skip; 3 = without the issue-priority schedule; 4 = skipping in row pairs only.  All but 1 need a workspace `plan` of imdct_plan_bytes(plan_groups) bytes,
 // plan_groups >= ch (launches with more (frame group, channel) units go through it in batches).
 uint64_t imdct_plan_bytes(uint32_t groups);
 hipError_t launch_imdct_rows(const DeviceTables &t, const DecodeRows &rows, uint32_t row_begin,

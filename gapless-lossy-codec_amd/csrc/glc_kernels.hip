@@ -518,21 +518,59 @@ __device__ __forceinline__ void d1_mac2rows_s(d1x2 (&c0)[4], d1x2 (&c1)[4], d1u2
       : "s"(a), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
 }
 
+// The same block with a scalar branch around each row's half: a row that lacks the entry (+0.0, bits
+// 0) costs two scalar instructions instead of 4 + 4 packed ones.  The branches live INSIDE the asm:
+// written as C++ control flow around two asm blocks, hipcc re-allocates the 64 accumulators per arm
+// and spills (128 VGPRs + scratch, 156 us instead of 108).
+__device__ __forceinline__ void d1_mac2rows_fine_s(d1x2 (&c0)[4], d1x2 (&c1)[4], d1u2 a, d1x2 b0, d1x2 b1, d1x2 b2, d1x2 b3) {
+  d1x2 t0, t1, t2, t3;
+  asm volatile(
+      "s_cmp_lg_u32 %13, 0\n\t"
+      "s_cbranch_scc0 1f\n\t"
+      "v_pk_mul_f32 %8, %12, %15 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %9, %12, %16 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %10, %12, %17 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %11, %12, %18 op_sel_hi:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, %8\n\t"
+      "v_pk_add_f32 %1, %1, %9\n\t"
+      "v_pk_add_f32 %2, %2, %10\n\t"
+      "v_pk_add_f32 %3, %3, %11\n"
+      "1:\n\t"
+      "s_cmp_lg_u32 %14, 0\n\t"
+      "s_cbranch_scc0 2f\n\t"
+      "v_pk_mul_f32 %8, %12, %15 op_sel:[1,0]\n\t"
+      "v_pk_mul_f32 %9, %12, %16 op_sel:[1,0]\n\t"
+      "v_pk_mul_f32 %10, %12, %17 op_sel:[1,0]\n\t"
+      "v_pk_mul_f32 %11, %12, %18 op_sel:[1,0]\n\t"
+      "v_pk_add_f32 %4, %4, %8\n\t"
+      "v_pk_add_f32 %5, %5, %9\n\t"
+      "v_pk_add_f32 %6, %6, %10\n\t"
+      "v_pk_add_f32 %7, %7, %11\n"
+      "2:"
+      : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3]),
+        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "s"(a), "s"(a.x), "s"(a.y), "v"(b0), "v"(b1), "v"(b2), "v"(b3)
+      : "scc");
+}
+
 // Two table rows per wave in registers: the one being applied and the next, in flight (four were
 // measured and bought nothing: tools/d1_tune.hip, profiles/r02_d1_*).
-template <bool SKIP, bool PRIO = true>
+template <bool SKIP, bool PRIO = true, bool FINE = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_imdct_apply(DeviceTables tb, const unsigned *__restrict__ plan_hdr, const unsigned *__restrict__ plan_rec,
-                   unsigned n_frames, unsigned ch, unsigned group_begin, unsigned n_groups, float *__restrict__ blocks) {
+                   unsigned n_frames, unsigned ch, unsigned group_begin, unsigned n_units, float *__restrict__ blocks) {
   constexpr int G = 8, R = 2;
-  // block -> (frame group, channel) of this batch: workgroups are dealt round-robin over the 8 XCDs
-  // (blockIdx % 8), and channels can differ in how many coefficients they keep, so every XCD takes
-  // frame groups of ALL channels: block 8 q + x handles channel q % ch of frame group (q / ch) * 8 + x.
-  // The grid is padded to a multiple of 8 frame groups; surplus blocks leave.  (Speed only.)
-  const unsigned q_ = blockIdx.x >> 3;
-  const unsigned c = q_ % ch;
-  const unsigned fg = (q_ / ch) * 8u + (blockIdx.x & 7u);  // frame group within the batch
-  if (fg >= n_groups) return;
+  // block -> unit (frame group, channel) of this batch.  (Speed only.)  All units of a launch of
+  // <= 1024 are resident at once, four to a CU, and the dispatcher deals an empty chip so that blocks
+  // b, b + 256, b + 512, b + 768 share a CU (measured: tools/d1_tune.hip prints the hardware ids).
+  // Channels can differ in how many coefficients they keep (config 2: 985 against 1146 stored
+  // non-zeros + union entries per unit), so the natural order - which hands a CU four units of ONE
+  // channel whenever 256 % ch == 0 - leaves the slowest CU 14 % above the mean; rotating the channel
+  // by the round (b / 256) of the frame group's first block gives every CU all channels (7 % above;
+  // a full sort by work would reach 4 % but costs more than it returns: 10 us in the plan kernel).
+  const unsigned fg = blockIdx.x / ch;
+  const unsigned c = (blockIdx.x - fg * ch + ((fg * ch) >> 8)) % ch;
+  if (blockIdx.x >= n_units) return;
   const unsigned local = fg * ch + c;
   const unsigned fr0 = (group_begin + fg) * G;
   const unsigned *hdr = plan_hdr + static_cast<size_t>(local) * kPlanHdrDwords;
@@ -540,13 +578,12 @@ void k_imdct_apply(DeviceTables tb, const unsigned *__restrict__ plan_hdr, const
   const unsigned live = __builtin_amdgcn_readfirstlane(hdr[1]);
   if (!live) return;
   // The four waves of a SIMD are arbitrated oldest-first, so left alone they finish one after the
-  // other (at 25 / 50 / 75 / 100 % of the kernel) and the last one runs by itself, with nobody to
-  // fill its scalar and wait slots.  Each wave therefore lowers its own issue priority as it gets
-  // through its union (3 in the first quarter ... 0 in the last): whoever is furthest behind goes
-  // first, the waves of a SIMD progress together and keep covering each other's stalls to the end
-  // (config 2: 120 -> 112 us; fully shared indices: 102 -> 90 us).  Only for units whose rows share
-  // most indices: when entries are mostly one row pair long the steps are too short for this to pay
-  // (0 % shared: 224 -> 246 us with it), so the plan kernel flags the dense units.
+  // other and the last one runs by itself, with nobody to fill its scalar and wait slots.  Each wave
+  // of a dense unit therefore lowers its own issue priority as it gets through its union (3 in the
+  // first quarter ... 0 in the last): whoever is furthest behind goes first, the waves of a SIMD
+  // progress together and keep covering each other's stalls to the end (config 2: D1 106 -> 92 us
+  // with the per-row skip in place, 80 -> 76 us with fully shared indices; debug variant 3 is the
+  // kernel without it).  Only for units whose rows share most indices, flagged by the plan kernel.
   const unsigned dense_unit = PRIO ? __builtin_amdgcn_readfirstlane(hdr[6]) : 0u;
   const unsigned q1 = n_u >> 2, q2 = n_u >> 1, q3 = q1 + q2;
   unsigned prio_next = dense_unit ? q1 : 0xFFFFFFFFu, prio_level = 0;  // scalar state: one compare per 4 entries
@@ -595,14 +632,22 @@ void k_imdct_apply(DeviceTables tb, const unsigned *__restrict__ plan_hdr, const
 #define GLC_D1_WAIT2(C0, K0, C1, K1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(C0), "+s"(K0), "+s"(C1), "+s"(K1)::"memory")
   // One entry.  S: its table slot; CC: its 8 coefficients; KC: table offset of entry J + R, whose row
   // refills slot S.  Of the table loads only those of the R - 1 following entries may be in flight.
+#define GLC_D1_PAIR(S, P, A0, A1)                                                                                \
+  do {                                                                                                          \
+    if (SKIP && FINE) {                                                                                          \
+      if (P.x | P.y) d1_mac2rows_fine_s(acc[A0], acc[A1], P, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);      \
+    } else if (!SKIP || (P.x | P.y)) {                                                                           \
+      d1_mac2rows_s(acc[A0], acc[A1], P, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);                         \
+    }                                                                                                           \
+  } while (0)
 #define GLC_D1_ENTRY(S, CC, KC)                                                                                  \
   do {                                                                                                          \
     asm volatile("s_waitcnt vmcnt(2)" : "+v"(t_lo[S]), "+v"(t_hi[S])::"memory");                                  \
     const d1u2 p0 = CC.s01, p1 = CC.s23, p2 = CC.s45, p3 = CC.s67;                                               \
-    if (!SKIP || (p0.x | p0.y)) d1_mac2rows_s(acc[0], acc[1], p0, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw); \
-    if (!SKIP || (p1.x | p1.y)) d1_mac2rows_s(acc[2], acc[3], p1, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw); \
-    if (!SKIP || (p2.x | p2.y)) d1_mac2rows_s(acc[4], acc[5], p2, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw); \
-    if (!SKIP || (p3.x | p3.y)) d1_mac2rows_s(acc[6], acc[7], p3, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw); \
+    GLC_D1_PAIR(S, p0, 0, 1);                                                                                    \
+    GLC_D1_PAIR(S, p1, 2, 3);                                                                                    \
+    GLC_D1_PAIR(S, p2, 4, 5);                                                                                    \
+    GLC_D1_PAIR(S, p3, 6, 7);                                                                                    \
     issue_tab(t_lo[S], t_hi[S], KC);                                                                             \
   } while (0)
   GLC_D1_FETCH2(ca, ka, cb, kb, 0);
@@ -638,6 +683,7 @@ void k_imdct_apply(DeviceTables tb, const unsigned *__restrict__ plan_hdr, const
     }
   }
 #undef GLC_D1_ENTRY
+#undef GLC_D1_PAIR
 #undef GLC_D1_FETCH2
 #undef GLC_D1_WAIT2
   // drain the run-ahead loads before their registers are reused
@@ -937,14 +983,17 @@ hipError_t launch_imdct_rows(const DeviceTables &t, const DecodeRows &rows, uint
   const uint32_t fg_per_batch = plan_groups / ch;
   for (uint32_t fg0 = 0; fg0 < groups; fg0 += fg_per_batch) {
     const uint32_t n_fg = groups - fg0 < fg_per_batch ? groups - fg0 : fg_per_batch;
-    const dim3 grid(((n_fg + 7) / 8) * 8 * ch);
-    hipLaunchKernelGGL(k_imdct_plan, dim3(n_fg * ch), dim3(256), 0, s, rows, row_begin, n_frames, ch, fg0, 2u, hdr, rec, blocks);
+    const uint32_t n_units = n_fg * ch;
+    const dim3 grid(n_units);
+    hipLaunchKernelGGL(k_imdct_plan, grid, dim3(256), 0, s, rows, row_begin, n_frames, ch, fg0, 2u, hdr, rec, blocks);
     if (variant == 2)
-      hipLaunchKernelGGL(k_imdct_apply<false>, grid, dim3(256), 0, s, t, hdr, rec, n_frames, ch, fg0, n_fg, blocks);
+      hipLaunchKernelGGL(k_imdct_apply<false>, grid, dim3(256), 0, s, t, hdr, rec, n_frames, ch, fg0, n_units, blocks);
+    else if (variant == 4)
+      hipLaunchKernelGGL((k_imdct_apply<true, true, false>), grid, dim3(256), 0, s, t, hdr, rec, n_frames, ch, fg0, n_units, blocks);
     else if (variant == 3)
-      hipLaunchKernelGGL((k_imdct_apply<true, false>), grid, dim3(256), 0, s, t, hdr, rec, n_frames, ch, fg0, n_fg, blocks);
+      hipLaunchKernelGGL((k_imdct_apply<true, false>), grid, dim3(256), 0, s, t, hdr, rec, n_frames, ch, fg0, n_units, blocks);
     else
-      hipLaunchKernelGGL(k_imdct_apply<true>, grid, dim3(256), 0, s, t, hdr, rec, n_frames, ch, fg0, n_fg, blocks);
+      hipLaunchKernelGGL(k_imdct_apply<true>, grid, dim3(256), 0, s, t, hdr, rec, n_frames, ch, fg0, n_units, blocks);
   }
   return hipGetLastError();
 }

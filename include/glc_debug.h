@@ -20,6 +20,7 @@ extern "C" {
  *   1  k_imdct_rows: one row per workgroup, no grouping (the simplest restatement)
  *   2  plan + apply without the skip (every row takes every union entry)
  *   3  plan + apply without the issue-priority schedule (waves of a SIMD finish one after the other)
+ *   4  plan + apply skipping absent rows only in pairs (both rows of a pair lack the entry)
  * All of them produce the same bits; tools/soak_decode.py checks that on random streams. */
 int glc_debug_set_imdct_variant(glc_ctx *ctx, int variant);
 

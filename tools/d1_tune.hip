@@ -15,6 +15,9 @@
 #include <cstdlib>
 #include <random>
 #include <string>
+#include <map>
+
+#include "glc_kernels.h"  // the library's own launch, linked in for a like-for-like run (family L)
 #include <vector>
 
 #include "glc_mdct_fwd.hpp"  // k1::mac2rows
@@ -640,20 +643,60 @@ void k_apply(const float *T, const float *win, float norm, const unsigned *plan_
   }
 }
 
+// mac2rows_s with a scalar branch around each row's half (absent = bits 0), branches inside the asm
+__device__ __forceinline__ void mac2rows_fine_s(d1x2 (&c0)[4], d1x2 (&c1)[4], u2v a, d1x2 b0, d1x2 b1, d1x2 b2, d1x2 b3) {
+  d1x2 t0, t1, t2, t3;
+  asm volatile(
+      "s_cmp_lg_u32 %13, 0\n\t"
+      "s_cbranch_scc0 1f\n\t"
+      "v_pk_mul_f32 %8, %12, %15 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %9, %12, %16 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %10, %12, %17 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %11, %12, %18 op_sel_hi:[0,1]\n\t"
+      "v_pk_add_f32 %0, %0, %8\n\t"
+      "v_pk_add_f32 %1, %1, %9\n\t"
+      "v_pk_add_f32 %2, %2, %10\n\t"
+      "v_pk_add_f32 %3, %3, %11\n"
+      "1:\n\t"
+      "s_cmp_lg_u32 %14, 0\n\t"
+      "s_cbranch_scc0 2f\n\t"
+      "v_pk_mul_f32 %8, %12, %15 op_sel:[1,0]\n\t"
+      "v_pk_mul_f32 %9, %12, %16 op_sel:[1,0]\n\t"
+      "v_pk_mul_f32 %10, %12, %17 op_sel:[1,0]\n\t"
+      "v_pk_mul_f32 %11, %12, %18 op_sel:[1,0]\n\t"
+      "v_pk_add_f32 %4, %4, %8\n\t"
+      "v_pk_add_f32 %5, %5, %9\n\t"
+      "v_pk_add_f32 %6, %6, %10\n\t"
+      "v_pk_add_f32 %7, %7, %11\n"
+      "2:"
+      : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3]),
+        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "s"(a), "s"(a.x), "s"(a.y), "v"(b0), "v"(b1), "v"(b2), "v"(b3)
+      : "scc");
+}
+
+
 // ------------------------------------------------------------------------------------------
 // Variant C2: apply with the records fetched TWO entries at a time, a whole pair of entries ahead
 // (scalar loads return out of order, so the only safe wait is lgkmcnt(0): fetching every other
 // entry doubles the slack of each wait), otherwise k_apply.
 // ------------------------------------------------------------------------------------------
-template <bool SKIP, int MINW, int R = 2>
+template <bool SKIP, int MINW, int R = 2, int PRIO = 0, bool FINE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
 void k_apply_pair(const float *T, const float *win, float norm, const unsigned *plan_hdr, const unsigned *plan_rec,
-                  unsigned n_frames, unsigned ch, float *blocks, unsigned long long *stamps = nullptr) {
+                  unsigned n_frames, unsigned ch, float *blocks, unsigned long long *stamps = nullptr,
+                  const unsigned *order = nullptr) {
   constexpr int G = 8;
   const unsigned long long t_start = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const unsigned q_ = blockIdx.x >> 3;
-  const unsigned c = q_ % ch;
-  const unsigned fgrp = (q_ / ch) * 8u + (blockIdx.x & 7u);
+  unsigned c = q_ % ch;
+  unsigned fgrp = (q_ / ch) * 8u + (blockIdx.x & 7u);
+  if (order) {  // block -> unit by a table (balanced placement experiment)
+    const unsigned g_ = __builtin_amdgcn_readfirstlane(order[blockIdx.x]);
+    if (g_ == 0xFFFFFFFFu) return;
+    fgrp = g_ / ch;
+    c = g_ % ch;
+  }
   const unsigned fr0 = fgrp * G;
   if (fr0 >= n_frames) return;
   const unsigned grp = fgrp * ch + c;
@@ -662,6 +705,11 @@ void k_apply_pair(const float *T, const float *win, float norm, const unsigned *
   const unsigned live = __builtin_amdgcn_readfirstlane(hdr[1]);
   const unsigned k0 = __builtin_amdgcn_readfirstlane(hdr[2]), k1 = __builtin_amdgcn_readfirstlane(hdr[3]);
   if (!live) return;
+  // PRIO 1: the library's ladder (dense units 3,2,1,0 by quarter; others stay at 3)
+  const unsigned dense_unit = PRIO ? (n_u < 200u ? 1u : 0u) : 0u;
+  const unsigned q1 = n_u >> 2, q2 = n_u >> 1, q3 = q1 + q2;
+  unsigned prio_next = dense_unit ? q1 : 0xFFFFFFFFu, prio_level = 0;
+  if (PRIO) __builtin_amdgcn_s_setprio(3);
   const unsigned *rec = plan_rec + static_cast<size_t>(grp) * kRecCap * kRecDwords;
   const unsigned col0 = static_cast<unsigned>(threadIdx.x) * 8u;
   const unsigned lane_off = col0 * 4u;
@@ -695,10 +743,14 @@ void k_apply_pair(const float *T, const float *win, float norm, const unsigned *
     if (R == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(t_lo[S]), "+v"(t_hi[S])::"memory");                    \
     else asm volatile("s_waitcnt vmcnt(6)" : "+v"(t_lo[S]), "+v"(t_hi[S])::"memory");                           \
     const u2v p0 = CC_.s01, p1 = CC_.s23, p2 = CC_.s45, p3 = CC_.s67;                                          \
-    if (!SKIP || (p0.x | p0.y)) mac2rows_s(acc[0], acc[1], p0, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);  \
-    if (!SKIP || (p1.x | p1.y)) mac2rows_s(acc[2], acc[3], p1, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);  \
-    if (!SKIP || (p2.x | p2.y)) mac2rows_s(acc[4], acc[5], p2, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);  \
-    if (!SKIP || (p3.x | p3.y)) mac2rows_s(acc[6], acc[7], p3, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);  \
+    if (SKIP && FINE) { if (p0.x | p0.y) mac2rows_fine_s(acc[0], acc[1], p0, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw); } \
+    else if (!SKIP || (p0.x | p0.y)) mac2rows_s(acc[0], acc[1], p0, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);  \
+    if (SKIP && FINE) { if (p1.x | p1.y) mac2rows_fine_s(acc[2], acc[3], p1, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw); } \
+    else if (!SKIP || (p1.x | p1.y)) mac2rows_s(acc[2], acc[3], p1, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);  \
+    if (SKIP && FINE) { if (p2.x | p2.y) mac2rows_fine_s(acc[4], acc[5], p2, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw); } \
+    else if (!SKIP || (p2.x | p2.y)) mac2rows_s(acc[4], acc[5], p2, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);  \
+    if (SKIP && FINE) { if (p3.x | p3.y) mac2rows_fine_s(acc[6], acc[7], p3, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw); } \
+    else if (!SKIP || (p3.x | p3.y)) mac2rows_s(acc[6], acc[7], p3, t_lo[S].xy, t_lo[S].zw, t_hi[S].xy, t_hi[S].zw);  \
     issue_tab(t_lo[S], t_hi[S], KC_);                                                                          \
   } while (0)
 #define FETCH2(C0, K0, C1, K1, J)                                                                             \
@@ -711,6 +763,13 @@ void k_apply_pair(const float *T, const float *win, float norm, const unsigned *
   unsigned j = 0;
 #pragma unroll 1
   for (; j + 4 <= n_u; j += 4) {
+    if (PRIO && j >= prio_next) {
+      ++prio_level;
+      if (prio_level == 1) __builtin_amdgcn_s_setprio(2);
+      else if (prio_level == 2) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+      prio_next = prio_level == 1 ? q2 : prio_level == 2 ? q3 : 0xFFFFFFFFu;
+    }
     WAIT2(ca, ka, cb, kb);
     FETCH2(cc, kc, cd, kd, j + 2);
     ENTRYP(0, ca, ka);
@@ -757,7 +816,9 @@ void k_apply_pair(const float *T, const float *win, float norm, const unsigned *
     o[2] = n_u;
     unsigned hw;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    o[3] = hw;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    o[3] = hw | (static_cast<unsigned long long>(xcc) << 32);
   }
 }
 
@@ -1070,17 +1131,60 @@ int main(int argc, char **argv) {
     hipLaunchKernelGGL(k_plan, dim3(g8), dim3(256), 0, st, R, nf, ch, d_hdr, d_prec, 4u);
     hipLaunchKernelGGL((k_apply_pair<true, 4, 4>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, (unsigned long long *)nullptr);
   });
+  run("C2 apply_pair alone + priority ladder", true, [&] {
+    hipLaunchKernelGGL((k_apply_pair<true, 4, 2, 1, false>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, (unsigned long long *)nullptr);
+  });
+  run("C2 apply_pair alone + priority ladder + per-row skip (shipped)", true, [&] {
+    hipLaunchKernelGGL((k_apply_pair<true, 4, 2, 1, true>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, (unsigned long long *)nullptr);
+  });
   run("C2 apply_pair R=4 alone", true, [&] {
     hipLaunchKernelGGL((k_apply_pair<true, 4, 4>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, (unsigned long long *)nullptr);
   });
   hipLaunchKernelGGL(k_plan, dim3(g8), dim3(256), 0, st, R, nf, ch, d_hdr, d_prec, 2u);  // back to the R = 2 plan
+  unsigned *d_order = nullptr;
+  {  // balanced placement: blocks b, b + 256, b + 512, b + 768 share a CU (measured: the dispatcher deals an empty
+     // chip in that order), so units are sorted by work and dealt in a snake over the 256 CU slots
+    const unsigned n_units = ((nf + 7) / 8) * ch;
+    std::vector<std::pair<unsigned, unsigned>> wk;  // (work, unit)
+    for (unsigned fgp = 0; fgp < (nf + 7) / 8; ++fgp)
+      for (unsigned c = 0; c < ch; ++c) {
+        std::vector<char> seen(1024, 0);
+        unsigned nu = 0, tot = 0;
+        for (unsigned f = fgp * 8; f < std::min(nf, fgp * 8 + 8); ++f) {
+          tot += cnt[f * ch + c];
+          for (unsigned k : row_idx[f * ch + c])
+            if (!seen[k]) seen[k] = 1, ++nu;
+        }
+        const unsigned alpha = getenv("D1_TUNE_ALPHA") ? atoi(getenv("D1_TUNE_ALPHA")) : 1;
+        wk.push_back({tot + alpha * nu, fgp * ch + c});
+      }
+    std::sort(wk.begin(), wk.end(), [](auto &a, auto &b) { return a.first > b.first; });
+    std::vector<unsigned> order(gridC, 0xFFFFFFFFu);
+    for (unsigned i = 0; i < n_units && i < gridC; ++i) {
+      const unsigned round = i / 256, pos = i % 256;
+      const unsigned slot = (round & 1) ? 255 - pos : pos;
+      order[round * 256 + slot] = wk[i].second;
+    }
+    CHECK(hipMalloc(&d_order, gridC * 4));
+    CHECK(hipMemcpy(d_order, order.data(), gridC * 4, hipMemcpyHostToDevice));
+  }
+  run("C2 apply_pair alone, shipped + balanced placement (snake over CU slots)", true, [&] {
+    hipLaunchKernelGGL((k_apply_pair<true, 4, 2, 1, true>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, (unsigned long long *)nullptr, d_order);
+  });
+  run("C2 apply_pair alone, shipped (again)", true, [&] {
+    hipLaunchKernelGGL((k_apply_pair<true, 4, 2, 1, true>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, (unsigned long long *)nullptr);
+  });
+  run("C2 apply_pair alone, shipped + balanced placement (again)", true, [&] {
+    hipLaunchKernelGGL((k_apply_pair<true, 4, 2, 1, true>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, (unsigned long long *)nullptr, d_order);
+  });
   {  // per-wave timeline of one apply_pair launch: when do waves end, and which are the last?
     unsigned long long *d_st;
     const size_t nw = size_t(gridC) * 4;
     CHECK(hipMalloc(&d_st, nw * 32));
     CHECK(hipMemset(d_st, 0, nw * 32));
     for (int i = 0; i < 3; ++i)
-      hipLaunchKernelGGL((k_apply_pair<true, 4>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, d_st);
+      hipLaunchKernelGGL((k_apply_pair<true, 4, 2, 1, true>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, d_st,
+                         getenv("D1_TUNE_TIMELINE_BALANCED") ? d_order : (const unsigned *)nullptr);
     CHECK(hipStreamSynchronize(st));
     std::vector<unsigned long long> hs(nw * 4);
     CHECK(hipMemcpy(hs.data(), d_st, nw * 32, hipMemcpyDeviceToHost));
@@ -1107,11 +1211,81 @@ int main(int argc, char **argv) {
       printf("  last #%d: block %zu wave %zu n_u %llu start %.1f end %.1f us  hw_id 0x%08x (cu %u sh %u se %u simd %u)\n", i, w / 4, w % 4, hs[w * 4 + 2],
              (hs[w * 4] - t0) * 0.01, (hs[w * 4 + 1] - t0) * 0.01, hw, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7, (hw >> 4) & 3);
     }
+    {  // per CU (XCD = block % 8 | se | sh | cu): when does its last wave end, and how much union did it get?
+      std::map<unsigned, std::pair<double, unsigned long long>> cu;  // key -> (last end, sum of n_u over its waves)
+      std::map<unsigned, std::vector<double>> simd_ends;
+      for (size_t w = 0; w < nw; ++w) {
+        if (!hs[w * 4 + 1]) continue;
+        const unsigned hw = (unsigned)hs[w * 4 + 3];
+        const unsigned key = (unsigned)((hs[w * 4 + 3] >> 32) & 15) << 16 | ((hw >> 8) & 0xFF) << 4;
+        auto &e = cu[key];
+        e.first = std::max(e.first, (hs[w * 4 + 1] - t0) * 0.01);
+        e.second += hs[w * 4 + 2];
+        simd_ends[key | ((hw >> 4) & 3)].push_back((hs[w * 4 + 1] - t0) * 0.01);
+      }
+      std::vector<double> ce, cws;
+      for (auto &kv : cu) ce.push_back(kv.second.first), cws.push_back((double)kv.second.second);
+      std::sort(ce.begin(), ce.end());
+      std::sort(cws.begin(), cws.end());
+      printf("  %zu CUs seen; last wave of a CU ends at: min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f us; union entries x waves per CU: min %.0f p50 %.0f max %.0f\n",
+             ce.size(), ce.front(), ce[ce.size() / 10], ce[ce.size() / 2], ce[ce.size() * 9 / 10], ce.back(), cws.front(), cws[cws.size() / 2], cws.back());
+      double acc4[4] = {0, 0, 0, 0};
+      size_t n4 = 0, nwaves_hist[9] = {0};
+      for (auto &kv : simd_ends) {
+        auto v = kv.second;
+        std::sort(v.begin(), v.end());
+        ++nwaves_hist[std::min<size_t>(v.size(), 8)];
+        if (v.size() == 4) { for (int i = 0; i < 4; ++i) acc4[i] += v[i]; ++n4; }
+      }
+      printf("  waves per SIMD histogram:");
+      for (int i = 0; i < 9; ++i) printf(" %d:%zu", i, nwaves_hist[i]);
+      printf("\n  SIMDs with 4 waves (%zu): mean end of the 1st..4th wave to finish: %.1f %.1f %.1f %.1f us\n", n4, n4 ? acc4[0] / n4 : 0, n4 ? acc4[1] / n4 : 0,
+             n4 ? acc4[2] / n4 : 0, n4 ? acc4[3] / n4 : 0);
+    }
+    printf("  block -> (xcc, se, sh, cu) of its wave 0:");
+    for (size_t b = 0; b < 80 && b < nw / 4; ++b) {
+      const unsigned long long v = hs[b * 16 + 3];
+      const unsigned hw = (unsigned)v;
+      if (b % 8 == 0) printf("\n   %3zu:", b);
+      printf(" (%llu,%u,%u,%2u)", (v >> 32) & 15, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15);
+    }
+    printf("\n");
+    {  // do blocks b and b + 256 k share a CU?
+      size_t same = 0, tot = 0;
+      for (size_t b = 0; b + 256 < nw / 4; ++b) {
+        const unsigned long long v0 = hs[b * 16 + 3], v1 = hs[(b + 256) * 16 + 3];
+        if (!hs[b * 16 + 1] || !hs[(b + 256) * 16 + 1]) continue;
+        ++tot;
+        if (((v0 >> 32) & 15) == ((v1 >> 32) & 15) && (((unsigned)v0 >> 8) & 0xFF) == (((unsigned)v1 >> 8) & 0xFF)) ++same;
+      }
+      printf("  blocks b and b + 256 on the same CU: %zu of %zu\n", same, tot);
+    }
     // lifetime vs n_u
     double s_lo = 0, s_hi = 0; int c_lo = 0, c_hi = 0;
     for (size_t w = 0; w < nw; ++w)
       if (hs[w * 4 + 1]) { if (hs[w * 4 + 2] < 200) s_lo += (hs[w * 4 + 1] - hs[w * 4]) * 0.01, ++c_lo; else s_hi += (hs[w * 4 + 1] - hs[w * 4]) * 0.01, ++c_hi; }
     printf("  mean lifetime: n_u < 200: %.1f us (%d waves), n_u >= 200: %.1f us (%d waves)\n", c_lo ? s_lo / c_lo : 0, c_lo, c_hi ? s_hi / c_hi : 0, c_hi);
+  }
+  {  // family L: the library's launch_imdct_rows (csrc/glc_kernels.hip linked into this binary) on the same buffers
+    long long *d_rowraw;
+    unsigned long long *d_rawlen;
+    void *d_lplan;
+    CHECK(hipMalloc(&d_rowraw, M * 8));
+    CHECK(hipMalloc(&d_rawlen, M * 8));
+    CHECK(hipMemset(d_rowraw, 0xFF, M * 8));  // -1: no raw rows
+    CHECK(hipMemset(d_rawlen, 0, M * 8));
+    CHECK(hipMalloc(&d_lplan, glc::imdct_plan_bytes(2048)));
+    glc::DeviceTables tb{};
+    tb.cos = dT;
+    tb.window = dw;
+    tb.norm = norm;
+    glc::DecodeRows LR{d_pairs, reinterpret_cast<const uint64_t *>(d_begin), d_cnt, d_scale, reinterpret_cast<const int64_t *>(d_rowraw),
+                       reinterpret_cast<const uint64_t *>(d_rawlen), nullptr};
+    for (int v : {0, 4, 3, 2, 0}) {
+      char name[96];
+      snprintf(name, sizeof name, "L library plan + apply, debug variant %d", v);
+      run(name, true, [&] { CHECK(glc::launch_imdct_rows(tb, LR, 0, M, ch, d_out, st, v, d_lplan, 2048)); });
+    }
   }
   run("C apply alone (plan from the previous run) skip1", true, [&] {
     hipLaunchKernelGGL((k_apply<true, false, 4>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out);

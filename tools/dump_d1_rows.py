@@ -1,6 +1,7 @@
 """Writes the sparse rows of the BASELINE config-2 batch (4096 frames of the bench's 48 kHz stereo
 chord, encoded on the GPU) to build/d1_rows.bin for tools/d1_tune.hip: u32 {n_frames, channels, rows,
-n_pairs}, u64 begin[rows], u32 cnt[rows], f32 scale[rows], u32 pairs[n_pairs].
+n_pairs}, u64 begin[rows], u32 cnt[rows], f32 scale[rows], u32 pairs[n_pairs]; and the batch itself
+(interleaved f32) to build/chord_cfg2.f32 for the C++ drivers tools/encode_breakdown.cpp / decode_breakdown.cpp.
 Usage: python tools/dump_d1_rows.py [frames]"""
 import os
 import sys
@@ -36,6 +37,7 @@ cnt = blob[o_cnt:o_cnt + 4 * M].view(np.uint32)
 pairs = blob[o_pairs:o_pairs + 4 * info.n_pairs].view(np.uint32)
 begin = np.concatenate([[0], np.cumsum(cnt[:-1], dtype=np.uint64)]).astype(np.uint64)
 os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+x.tofile(os.path.join(ROOT, "build", "chord_cfg2.f32"))  # the batch itself, for tools/{en,de}code_breakdown.cpp
 with open(os.path.join(ROOT, "build", "d1_rows.bin"), "wb") as fh:
     fh.write(np.array([nf, CH, M, info.n_pairs], np.uint32).tobytes())
     fh.write(begin.tobytes())
