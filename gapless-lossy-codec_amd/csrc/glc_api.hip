@@ -7,11 +7,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <memory>
 #include <mutex>
 #include <new>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <cstdlib>
 #include <vector>
 
@@ -80,6 +83,9 @@ struct glc_ctx {
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;  // glc_ctx_timer_*
   hipStream_t copy_stream = nullptr;  // glc_encode: uploads run ahead of the kernels on this one
   hipEvent_t ev_copy = nullptr;
+  hipStream_t down_stream = nullptr;  // glc_encode: round i is compacted and its metadata comes down while round i+1 is transformed
+  hipStream_t pay_stream = nullptr;   // glc_encode: ... and the blob itself, fetched by the collecting thread
+  std::vector<hipEvent_t> ev_round;   // three per round: samples uploaded, records written, blob compacted
   glc::HostTables host;
   glc::DeviceTables dev{};
   DevBuf tables;     // all constant tables in one allocation
@@ -261,6 +267,10 @@ void glc_ctx_destroy(glc_ctx *ctx) {
   for (hipEvent_t e : ctx->ev_dec)
     if (e) (void)hipEventDestroy(e);
   ctx->stream_out.release();
+  for (hipEvent_t e : ctx->ev_round)
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->down_stream) (void)hipStreamDestroy(ctx->down_stream);
+  if (ctx->pay_stream) (void)hipStreamDestroy(ctx->pay_stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   ctx->tables.release();
@@ -389,7 +399,14 @@ int glc_mdct_forward_device(glc_ctx *ctx, const float *d_pcm, uint64_t t0, uint6
 
 // Queue the compaction of `n_frames` records into `d_blob` (capacity checked by the caller) on
 // the context's stream; nothing is synchronised.
-static int compact_launch(glc_ctx *ctx, const void *d_records, uint64_t n_frames, uint32_t ch, void *d_blob) {
+// scratch of one compaction of M rows: loc[M] | blk[nblk] | blk_raw[nblk] | totals, each 256-byte aligned
+static size_t compact_scratch_bytes(uint64_t M) {
+  const size_t nblk = (static_cast<size_t>(M) + 1023) / 1024;
+  return align_up(static_cast<size_t>(M) * 4, 256) + 2 * align_up(nblk * 8, 256) + 256;
+}
+
+static int compact_launch(glc_ctx *ctx, const void *d_records, uint64_t n_frames, uint32_t ch, void *d_blob,
+                          hipStream_t stream) {
   const uint64_t M64 = n_frames * ch;
   if (M64 > 0xFFFFFFFFull) return fail(ctx, GLC_EINVAL, "compaction: frame range too long");
   const uint32_t M = static_cast<uint32_t>(M64);
@@ -403,14 +420,14 @@ static int compact_launch(glc_ctx *ctx, const void *d_records, uint64_t n_frames
   };
   const size_t o_loc = place(static_cast<size_t>(M) * 4), o_blk = place(nblk * 8), o_blkr = place(nblk * 8);
   const size_t o_tot = place(16);
-  GLC_HIP(ctx, ctx->pack_meta.reserve(std::max<size_t>(off, 256)));
+  GLC_HIP(ctx, ctx->pack_meta.reserve(std::max<size_t>(off, compact_scratch_bytes(M))));
   uint8_t *mb = static_cast<uint8_t *>(ctx->pack_meta.p);
   uint8_t *blob = static_cast<uint8_t *>(d_blob);
-  GLC_HIP(ctx, hipMemsetAsync(blob, 0, l.o_pairs, ctx->stream));  // header + section padding: deterministic bytes
+  GLC_HIP(ctx, hipMemsetAsync(blob, 0, l.o_pairs, stream));  // header + section padding: deterministic bytes
   GLC_HIP(ctx, glc::launch_compact(static_cast<const uint8_t *>(d_records), M, ch, n_frames,
                                    reinterpret_cast<uint32_t *>(mb + o_loc), reinterpret_cast<uint64_t *>(mb + o_blk),
                                    reinterpret_cast<uint64_t *>(mb + o_blkr), reinterpret_cast<uint64_t *>(mb + o_tot),
-                                   blob, l.o_israw, l.o_scale, l.o_cnt, l.o_pairs, ctx->stream));
+                                   blob, l.o_israw, l.o_scale, l.o_cnt, l.o_pairs, stream));
   return GLC_OK;
 }
 
@@ -421,7 +438,7 @@ int glc_compact_device_records(glc_ctx *ctx, const void *d_records, uint64_t n_f
   const glc::CompactLayout l = glc::compact_layout(channels, n_frames);
   if (cap < l.bound) return fail(ctx, GLC_EINVAL, "glc_compact_device_records: blob buffer smaller than glc_compact_bound()");
   DeviceGuard guard(ctx->device);
-  int rc = compact_launch(ctx, d_records, n_frames, channels, d_blob);
+  int rc = compact_launch(ctx, d_records, n_frames, channels, d_blob, ctx->stream);
   if (rc != GLC_OK) return rc;
   glc::CompactHeader h;
   GLC_HIP(ctx, hipMemcpyAsync(&h, d_blob, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
@@ -513,48 +530,247 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
   const uint32_t ch = channels;
   const uint64_t rec = glc::record_bytes(ch);
   const uint64_t t_count = (n_samples + ch - 1) / ch;
-  GLC_HIP(ctx, ctx->pcm.reserve(static_cast<size_t>(t_count) * ch * sizeof(float)));
-  GLC_HIP(ctx, ctx->records.reserve(static_cast<size_t>(plan.n_frames) * rec));
-  // Upload and transform in rounds of at most kEncodeChunkFrames: round i's samples go up on the copy
-  // stream while round i-1's kernels run, so the call costs max(PCIe, kernels) instead of their sum.
-  if (!ctx->copy_stream) GLC_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-  if (!ctx->ev_copy) GLC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_copy, hipEventDisableTiming));
-  GLC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // earlier work may still read the staging buffer
-  float *d_pcm = static_cast<float *>(ctx->pcm.p);
-  uint64_t copied = 0;  // interleaved samples already on the device
-  int rc = GLC_OK;
-  // The first round is the one whose upload nothing hides, so it is kept as small as the transform
-  // stays efficient at: 4096 rows (the LDS-DMA kernel's threshold; it runs at 87 % of its full-batch
-  // rate there).  BASELINE config 2 (4096 stereo frames) becomes two rounds: the second half goes up
-  // while the first is transformed - 1.48 -> 1.25 ms per call.
+  // A pipeline over rounds of at most kEncodeChunkFrames frames.  Every stage has its own stream AND
+  // its own host thread, because two of the stages block their caller: a copy from or to pageable
+  // memory returns when it is done.
+  //   uploader thread   round i+1's samples go up, back to back                      (copy_stream)
+  //   launcher thread   round i is transformed and quantised as soon as it is up     (the context's stream)
+  //                     ... and compacted beside the next round's transform          (down_stream)
+  //   this thread       round i-1's blob comes down: metadata, then the payload straight into the
+  //                     EncodedAudio's pools, and is indexed                         (pay_stream)
+  // PCIe is full duplex and the compaction kernels are small, so a call costs
+  // max(upload, kernels) + the first upload + the last round's compaction and download instead of
+  // their sum.  Copies are issued only when their data is ready (never queued behind an unfinished
+  // dependency: the copy engines execute in submission order).  The first round is the one whose
+  // upload nothing hides, so it is kept as small as the transform stays efficient at: 4096 rows (the
+  // LDS-DMA kernel's threshold; it runs at 87 % of its full-batch rate there).  BASELINE config 2
+  // (4096 stereo frames) becomes two rounds; a stream of one round runs on this thread alone.
   const uint64_t first_round = std::min<uint64_t>(kEncodeChunkFrames, (4096 + ch - 1) / ch);
   const bool split_first = plan.n_frames >= 2 * first_round;
-  for (uint64_t f = 0, nf = 0; f < plan.n_frames && rc == GLC_OK; f += nf) {
-    nf = std::min<uint64_t>(f == 0 && split_first ? first_round : kEncodeChunkFrames, plan.n_frames - f);
-    // frames [f, f+nf) read per-channel samples below 1024*(f+nf-1) - 512 + 2048
-    const uint64_t hi_t = std::min<uint64_t>(t_count, (f + nf - 1) * glc::kHop + glc::kFrame - glc::kHop / 2);
-    const uint64_t hi = std::min<uint64_t>(n_samples, hi_t * ch);
-    hipError_t e = hipSuccess;
-    if (hi > copied) {
-      e = hipMemcpyAsync(d_pcm + copied, pcm + copied, (hi - copied) * sizeof(float), hipMemcpyHostToDevice,
-                         ctx->copy_stream);
-      copied = hi;
+  struct Round {
+    uint64_t f0, nf, blob_off, hi;  // hi: interleaved samples that must be on the device before its kernels run
+    glc::CompactLayout l;
+  };
+  std::vector<Round> rounds;
+  std::unique_ptr<glc_frames> F;
+  uint64_t max_nf = 0;
+  try {
+    uint64_t blob_off = 0;
+    for (uint64_t f = 0, nf = 0; f < plan.n_frames; f += nf) {
+      nf = std::min<uint64_t>(f == 0 && split_first ? first_round : kEncodeChunkFrames, plan.n_frames - f);
+      // frames [f, f+nf) read per-channel samples below 1024*(f+nf-1) - 512 + 2048
+      const uint64_t hi_t = std::min<uint64_t>(t_count, (f + nf - 1) * glc::kHop + glc::kFrame - glc::kHop / 2);
+      Round r{f, nf, blob_off, std::min<uint64_t>(n_samples, hi_t * ch), glc::compact_layout(ch, nf)};
+      blob_off += align_up(r.l.bound, 256);
+      max_nf = std::max(max_nf, nf);
+      rounds.push_back(r);
     }
-    if (e == hipSuccess) e = hipEventRecord(ctx->ev_copy, ctx->copy_stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_copy, 0);
-    if (e != hipSuccess) {
-      rc = hip_fail(ctx, e, "glc_encode: upload");
-      break;
+    F.reset(new glc_frames);
+    F->sample_rate = ctx->sample_rate;
+    F->channels = channels;
+    F->total_samples = n_samples;           // src/codec.rs:423,555
+    F->encoder_delay = plan.encoder_delay;  // :547
+    F->padding = plan.padding;              // :546
+    F->original_length = n_samples;         // :562
+    F->n_frames = plan.n_frames;
+    F->list_begin.assign(plan.n_frames + 1, 0);
+    F->scale_begin.assign(plan.n_frames + 1, 0);
+    F->raw_begin.assign(plan.n_frames + 1, 0);
+    F->raw_tag.resize(plan.n_frames);
+    F->list_off.reserve(plan.n_frames * ch + 1);
+    F->scales.reserve(plan.n_frames * ch);
+  } catch (const std::bad_alloc &) {
+    return fail(ctx, GLC_ENOMEM, "glc_encode: host allocation failed");
+  }
+  const size_t n_rounds = rounds.size();
+  const size_t meta_cap = align_up(glc::compact_layout(ch, max_nf).o_pairs, 256);
+  GLC_HIP(ctx, ctx->pcm.reserve(static_cast<size_t>(t_count) * ch * sizeof(float)));
+  GLC_HIP(ctx, ctx->records.reserve(static_cast<size_t>(plan.n_frames) * rec));
+  GLC_HIP(ctx, ctx->pack_blob.reserve(rounds.back().blob_off + align_up(rounds.back().l.bound, 256)));
+  GLC_HIP(ctx, ctx->host_stage.reserve(meta_cap));
+  // the per-round workspaces at their largest now: growing one mid-pipeline would free it under queued work
+  GLC_HIP(ctx, ctx->coef.reserve(static_cast<size_t>(max_nf) * ch * glc::kHop * sizeof(float)));
+  GLC_HIP(ctx, ctx->pack_meta.reserve(compact_scratch_bytes(max_nf * ch)));
+  if (!ctx->copy_stream) GLC_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  if (!ctx->down_stream) GLC_HIP(ctx, hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
+  if (!ctx->pay_stream) GLC_HIP(ctx, hipStreamCreateWithFlags(&ctx->pay_stream, hipStreamNonBlocking));
+  while (ctx->ev_round.size() < 3 * n_rounds) {
+    hipEvent_t e = nullptr;
+    GLC_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    try {
+      ctx->ev_round.push_back(e);
+    } catch (const std::bad_alloc &) {
+      (void)hipEventDestroy(e);
+      return fail(ctx, GLC_ENOMEM, "glc_encode: host allocation failed");
     }
-    rc = glc_encode_range_device(ctx, d_pcm, 0, t_count, n_samples, channels, f, f + nf,
-                                 static_cast<uint8_t *>(ctx->records.p) + f * rec, nullptr);
+  }
+  GLC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // earlier work may still read the staging buffers
+  float *d_pcm = static_cast<float *>(ctx->pcm.p);
+  uint8_t *d_blob = static_cast<uint8_t *>(ctx->pack_blob.p);
+  uint8_t *h_meta = static_cast<uint8_t *>(ctx->host_stage.p);
+  hipEvent_t *ev_up = ctx->ev_round.data(), *ev_rec = ev_up + n_rounds, *ev_blob = ev_rec + n_rounds;
+
+  // progress shared by the three threads; an error anywhere stops all of them
+  struct Progress {
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t uploaded = 0, queued = 0;  // rounds whose upload event / blob event has been recorded
+    int rc = GLC_OK;
+    std::string msg;
+    void set_error(int code, const std::string &m) {
+      std::lock_guard<std::mutex> lk(mu);
+      if (rc == GLC_OK) rc = code, msg = m;
+      cv.notify_all();
+    }
+    // wait until *counter > i; false when another stage has failed
+    bool wait_for(const size_t &counter, size_t i) {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return counter > i || rc != GLC_OK; });
+      return rc == GLC_OK;
+    }
+    void advance(size_t &counter) {
+      std::lock_guard<std::mutex> lk(mu);
+      ++counter;
+      cv.notify_all();
+    }
+  } prog;
+  auto hip_msg = [](const char *what, hipError_t e) { return std::string(what) + ": " + hipGetErrorString(e); };
+
+  auto upload = [&] {  // stage 1
+    DeviceGuard g(ctx->device);
+    uint64_t copied = 0;
+    for (size_t i = 0; i < n_rounds; ++i) {
+      const Round &r = rounds[i];
+      hipError_t e = hipSuccess;
+      if (r.hi > copied)
+        e = hipMemcpyAsync(d_pcm + copied, pcm + copied, (r.hi - copied) * sizeof(float), hipMemcpyHostToDevice, ctx->copy_stream);
+      copied = std::max(copied, r.hi);
+      if (e == hipSuccess) e = hipEventRecord(ev_up[i], ctx->copy_stream);
+      if (e != hipSuccess) return prog.set_error(e == hipErrorOutOfMemory ? GLC_ENOMEM : GLC_EHIP, hip_msg("glc_encode: upload", e));
+      prog.advance(prog.uploaded);
+      { std::lock_guard<std::mutex> lk(prog.mu); if (prog.rc != GLC_OK) return; }
+    }
+  };
+  auto launch = [&] {  // stage 2
+    DeviceGuard g(ctx->device);
+    for (size_t i = 0; i < n_rounds; ++i) {
+      const Round &r = rounds[i];
+      if (!prog.wait_for(prog.uploaded, i)) return;
+      hipError_t e = hipStreamWaitEvent(ctx->stream, ev_up[i], 0);
+      if (e != hipSuccess) return prog.set_error(GLC_EHIP, hip_msg("glc_encode: queueing a round", e));
+      uint8_t *recs = static_cast<uint8_t *>(ctx->records.p) + r.f0 * rec;
+      int rc = glc_encode_range_device(ctx, d_pcm, 0, t_count, n_samples, channels, r.f0, r.f0 + r.nf, recs, nullptr);
+      if (rc == GLC_OK) {
+        e = hipEventRecord(ev_rec[i], ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->down_stream, ev_rec[i], 0);
+        if (e != hipSuccess) return prog.set_error(GLC_EHIP, hip_msg("glc_encode: queueing a round", e));
+        rc = compact_launch(ctx, recs, r.nf, ch, d_blob + r.blob_off, ctx->down_stream);
+      }
+      if (rc != GLC_OK) return prog.set_error(rc, ctx->err);
+      e = hipEventRecord(ev_blob[i], ctx->down_stream);
+      if (e != hipSuccess) return prog.set_error(GLC_EHIP, hip_msg("glc_encode: queueing a round", e));
+      prog.advance(prog.queued);
+    }
+  };
+  uint64_t p_used = 0, r_used = 0;  // the pools are grown ahead of need (below): what of them is filled
+  auto collect = [&] {  // stage 3
+    for (size_t i = 0; i < n_rounds; ++i) {
+      const Round &r = rounds[i];
+      if (i > 0) {
+        // Growing a pool zero-fills it: do that for this round while its kernels still run, from the
+        // density of the stream so far (+ 25 %); a round that turns out denser grows again below.
+        const double per_frame = static_cast<double>(p_used) / static_cast<double>(r.f0) * 1.25;
+        const uint64_t want = p_used + static_cast<uint64_t>(per_frame * static_cast<double>(r.nf)) + 1024;
+        if (F->pairs.size() < want) F->pairs.resize(want);
+      }
+      if (!prog.wait_for(prog.queued, i)) return;
+      hipError_t e = hipEventSynchronize(ev_blob[i]);
+      // header + raw flags + scale factors + list lengths: they say how long the payload is
+      if (e == hipSuccess) e = hipMemcpyAsync(h_meta, d_blob + r.blob_off, r.l.o_pairs, hipMemcpyDeviceToHost, ctx->pay_stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->pay_stream);
+      if (e != hipSuccess) return prog.set_error(GLC_EHIP, hip_msg("glc_encode: download", e));
+      glc::CompactHeader h;
+      std::memcpy(&h, h_meta, sizeof h);
+      if (h.magic != glc::kCompactMagic || h.n_frames != r.nf || h.channels != ch || h.bytes > r.l.bound ||
+          h.n_pairs > r.nf * ch * glc::kHop || h.n_raw_rows > r.nf * ch)
+        return prog.set_error(GLC_EHIP, "glc_encode: the device wrote an inconsistent compact header");
+      const uint8_t *blob = d_blob + r.blob_off;
+      const uint64_t p_at = p_used, r_at = r_used;
+      if (i == 0 && n_rounds > 1) {  // reserve the pools once from the first round's density (+ 30 %)
+        const double scale = static_cast<double>(plan.n_frames) / static_cast<double>(r.nf) * 1.3;
+        F->pairs.reserve(static_cast<size_t>(static_cast<double>(h.n_pairs) * scale) + 4096);
+        if (h.n_raw_rows) F->raw.reserve(static_cast<size_t>(static_cast<double>(h.n_raw_rows * glc::kFrame) * scale));
+      }
+      if (F->pairs.size() < p_at + h.n_pairs) F->pairs.resize(p_at + h.n_pairs);
+      if (F->raw.size() < r_at + h.n_raw_rows * glc::kFrame) F->raw.resize(r_at + h.n_raw_rows * glc::kFrame);
+      p_used += h.n_pairs;
+      r_used += h.n_raw_rows * glc::kFrame;
+      if (h.n_pairs) e = hipMemcpyAsync(F->pairs.data() + p_at, blob + r.l.o_pairs, h.n_pairs * 4, hipMemcpyDeviceToHost, ctx->pay_stream);
+      if (e == hipSuccess && h.n_raw_rows)
+        e = hipMemcpyAsync(F->raw.data() + r_at, blob + glc::compact_raw_offset(r.l, h.n_pairs), h.n_raw_rows * glc::kFrame * 2,
+                           hipMemcpyDeviceToHost, ctx->pay_stream);
+      bool canonical = true;
+      int rc = GLC_OK;
+      if (e == hipSuccess) rc = glc::index_compact_meta(F.get(), ch, h, h_meta, r.f0, p_at, r_at, /*trusted=*/true, &canonical);
+      // the pools may move when the next round grows them, and h_meta is reused: all of it has to have landed
+      const hipError_t e2 = hipStreamSynchronize(ctx->pay_stream);
+      if (e == hipSuccess) e = e2;
+      if (e != hipSuccess) return prog.set_error(GLC_EHIP, hip_msg("glc_encode: download", e));
+      if (rc != GLC_OK) return prog.set_error(rc, std::string("glc_encode: ") + glc_last_error(nullptr));
+    }
+  };
+
+  int rc = GLC_OK;
+  std::string msg;
+  try {
+    if (n_rounds == 1) {
+      upload();
+      launch();
+      collect();
+    } else {
+      std::thread t_up(upload);
+      std::thread t_launch;
+      try {
+        t_launch = std::thread(launch);
+      } catch (...) {
+        prog.set_error(GLC_ENOMEM, "glc_encode: cannot start a thread");
+        t_up.join();
+        throw;
+      }
+      try {
+        collect();
+      } catch (...) {
+        prog.set_error(GLC_ENOMEM, "glc_encode: host allocation failed");
+      }
+      t_up.join();
+      t_launch.join();
+    }
+    std::lock_guard<std::mutex> lk(prog.mu);
+    rc = prog.rc;
+    msg = prog.msg;
+  } catch (const std::bad_alloc &) {
+    rc = GLC_ENOMEM, msg = "glc_encode: host allocation failed";
+  } catch (const std::system_error &) {
+    rc = GLC_ENOMEM, msg = "glc_encode: cannot start a thread";
   }
   if (rc != GLC_OK) {
+    // nothing may still be in flight into the caller's or the result's memory when this returns
     (void)hipStreamSynchronize(ctx->copy_stream);
-    return rc;
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->down_stream);
+    (void)hipStreamSynchronize(ctx->pay_stream);
+    return fail(ctx, rc, msg);
   }
-  // compact on the device; only pairs / scales / raw planes cross PCIe
-  return glc_frames_from_device_records(ctx, ctx->records.p, plan.n_frames, n_samples, channels, out);
+  try {
+    F->pairs.resize(p_used);  // shrinks: the pools were grown ahead of need
+    F->raw.resize(r_used);
+    F->list_off.push_back(F->pairs.size());
+  } catch (const std::bad_alloc &) {
+    return fail(ctx, GLC_ENOMEM, "glc_encode: host allocation failed");
+  }
+  F->lists_canonical = true;  // ballot-packed in ascending k
+  *out = F.release();
+  return GLC_OK;
 }
 
 // ------------------------------------------------------------------------------ decode

@@ -795,36 +795,43 @@ __global__ __launch_bounds__(256) void k_pack_scan_rows(const unsigned char *__r
   }
 }
 
-__global__ __launch_bounds__(1024) void k_pack_scan_blocks(unsigned long long *__restrict__ blk, unsigned n,
-                                                            unsigned long long *__restrict__ total) {
+// One workgroup: exclusive scans of the per-block pair counts and raw-row counts, their totals, and
+// the blob header they determine (three dependent launches of a few microseconds each before).
+__global__ __launch_bounds__(1024) void k_pack_scan_blocks(unsigned long long *__restrict__ blk,
+                                                            unsigned long long *__restrict__ blk_raw, unsigned n,
+                                                            unsigned long long *__restrict__ totals, unsigned ch,
+                                                            unsigned long long n_frames, unsigned long long o_pairs,
+                                                            unsigned char *__restrict__ blob) {
   __shared__ unsigned long long s[1024];
-  unsigned long long carry = 0;
-  for (unsigned b0 = 0; b0 < n; b0 += 1024) {
-    const unsigned i = b0 + threadIdx.x;
-    const unsigned long long mine = i < n ? blk[i] : 0ull;
-    s[threadIdx.x] = mine;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-      unsigned long long t = threadIdx.x >= static_cast<unsigned>(off) ? s[threadIdx.x - off] : 0ull;
+  unsigned long long sums[2];
+#pragma unroll 1
+  for (int which = 0; which < 2; ++which) {
+    unsigned long long *v = which ? blk_raw : blk;
+    unsigned long long carry = 0;
+    for (unsigned b0 = 0; b0 < n; b0 += 1024) {
+      const unsigned i = b0 + threadIdx.x;
+      const unsigned long long mine = i < n ? v[i] : 0ull;
+      s[threadIdx.x] = mine;
       __syncthreads();
-      s[threadIdx.x] += t;
+      for (int off = 1; off < 1024; off <<= 1) {
+        unsigned long long t = threadIdx.x >= static_cast<unsigned>(off) ? s[threadIdx.x - off] : 0ull;
+        __syncthreads();
+        s[threadIdx.x] += t;
+        __syncthreads();
+      }
+      if (i < n) v[i] = carry + s[threadIdx.x] - mine;  // exclusive
+      const unsigned long long chunk_total = s[1023];
       __syncthreads();
+      carry += chunk_total;
     }
-    if (i < n) blk[i] = carry + s[threadIdx.x] - mine;  // exclusive
-    const unsigned long long chunk_total = s[1023];
-    __syncthreads();
-    carry += chunk_total;
+    sums[which] = carry;
   }
-  if (threadIdx.x == 0) *total = carry;
-}
-
-__global__ __launch_bounds__(64) void k_pack_header(const unsigned long long *__restrict__ totals, unsigned ch,
-                                                     unsigned long long n_frames, unsigned long long o_pairs,
-                                                     unsigned char *__restrict__ blob) {
-  const unsigned long long n_pairs = totals[0], n_raw_rows = totals[1];
+  const unsigned long long n_pairs = sums[0], n_raw_rows = sums[1];
   const unsigned long long pairs_end = o_pairs + 4ull * n_pairs;
   const unsigned long long raw_off = (pairs_end + 63ull) & ~63ull;
   if (threadIdx.x == 0) {
+    totals[0] = n_pairs;
+    totals[1] = n_raw_rows;
     unsigned long long *h = reinterpret_cast<unsigned long long *>(blob);
     h[0] = 0x42434C47ull | (static_cast<unsigned long long>(ch) << 32);  // magic, channels
     h[1] = n_frames;
@@ -833,7 +840,7 @@ __global__ __launch_bounds__(64) void k_pack_header(const unsigned long long *__
     h[4] = raw_off + n_raw_rows * 4096ull;
     h[5] = h[6] = h[7] = 0ull;
   }
-  if (pairs_end + threadIdx.x < raw_off) blob[pairs_end + threadIdx.x] = 0;  // deterministic padding
+  if (threadIdx.x < 64 && pairs_end + threadIdx.x < raw_off) blob[pairs_end + threadIdx.x] = 0;  // deterministic padding
 }
 
 __global__ __launch_bounds__(256) void k_pack_rows(const unsigned char *__restrict__ records, unsigned M,
@@ -937,10 +944,9 @@ hipError_t launch_compact(const uint8_t *records, uint32_t M, uint32_t ch, uint6
                           uint64_t *blk, uint64_t *blk_raw, uint64_t *totals, uint8_t *blob, uint64_t o_israw,
                           uint64_t o_scale, uint64_t o_cnt, uint64_t o_pairs, hipStream_t s) {
   auto *t = reinterpret_cast<unsigned long long *>(totals);
-  if (M == 0) {
-    hipError_t e = hipMemsetAsync(totals, 0, 2 * sizeof(uint64_t), s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_pack_header, dim3(1), dim3(64), 0, s, t, ch, 0ull, o_pairs, blob);
+  if (M == 0) {  // an empty range: the scans are over nothing, the header says so
+    hipLaunchKernelGGL(k_pack_scan_blocks, dim3(1), dim3(1024), 0, s, reinterpret_cast<unsigned long long *>(blk),
+                       reinterpret_cast<unsigned long long *>(blk_raw), 0u, t, ch, 0ull, static_cast<unsigned long long>(o_pairs), blob);
     return hipGetLastError();
   }
   const unsigned long long hdr = ((8ull + 8ull * ch) + 15ull) & ~15ull;
@@ -951,9 +957,7 @@ hipError_t launch_compact(const uint8_t *records, uint32_t M, uint32_t ch, uint6
   hipLaunchKernelGGL(k_pack_scan_rows, dim3(nblk), dim3(256), 0, s, records, M, ch, rec, loc, b, br,
                      reinterpret_cast<float *>(blob + o_scale), reinterpret_cast<unsigned *>(blob + o_cnt),
                      blob + o_israw);
-  hipLaunchKernelGGL(k_pack_scan_blocks, dim3(1), dim3(1024), 0, s, b, nblk, t);
-  hipLaunchKernelGGL(k_pack_scan_blocks, dim3(1), dim3(1024), 0, s, br, nblk, t + 1);
-  hipLaunchKernelGGL(k_pack_header, dim3(1), dim3(64), 0, s, t, ch, static_cast<unsigned long long>(n_frames),
+  hipLaunchKernelGGL(k_pack_scan_blocks, dim3(1), dim3(1024), 0, s, b, br, nblk, t, ch, static_cast<unsigned long long>(n_frames),
                      static_cast<unsigned long long>(o_pairs), blob);
   hipLaunchKernelGGL(k_pack_rows, dim3((M + 3) / 4), dim3(256), 0, s, records, M, ch, rec, hdr, loc, b, br, t,
                      reinterpret_cast<const unsigned *>(blob + o_cnt), static_cast<unsigned long long>(o_pairs), blob);

@@ -685,7 +685,7 @@ template <bool SKIP, int MINW, int R = 2, int PRIO = 0, bool FINE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
 void k_apply_pair(const float *T, const float *win, float norm, const unsigned *plan_hdr, const unsigned *plan_rec,
                   unsigned n_frames, unsigned ch, float *blocks, unsigned long long *stamps = nullptr,
-                  const unsigned *order = nullptr) {
+                  const unsigned *order = nullptr, unsigned prio_step = 0) {
   constexpr int G = 8;
   const unsigned long long t_start = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const unsigned q_ = blockIdx.x >> 3;
@@ -707,8 +707,14 @@ void k_apply_pair(const float *T, const float *win, float norm, const unsigned *
   if (!live) return;
   // PRIO 1: the library's ladder (dense units 3,2,1,0 by quarter; others stay at 3)
   const unsigned dense_unit = PRIO ? (n_u < 200u ? 1u : 0u) : 0u;
-  const unsigned q1 = n_u >> 2, q2 = n_u >> 1, q3 = q1 + q2;
+  unsigned q1 = n_u >> 2, q2 = n_u >> 1, q3 = q1 + q2;
   unsigned prio_next = dense_unit ? q1 : 0xFFFFFFFFu, prio_level = 0;
+  if (PRIO == 2) {  // by entries REMAINING (every unit): 3 until 3 steps are left, then 2, 1, 0
+    q1 = n_u > 3 * prio_step ? n_u - 3 * prio_step : 0;
+    q2 = n_u > 2 * prio_step ? n_u - 2 * prio_step : 0;
+    q3 = n_u > prio_step ? n_u - prio_step : 0;
+    prio_next = q1;
+  }
   if (PRIO) __builtin_amdgcn_s_setprio(3);
   const unsigned *rec = plan_rec + static_cast<size_t>(grp) * kRecCap * kRecDwords;
   const unsigned col0 = static_cast<unsigned>(threadIdx.x) * 8u;
@@ -1171,6 +1177,13 @@ int main(int argc, char **argv) {
   run("C2 apply_pair alone, shipped + balanced placement (snake over CU slots)", true, [&] {
     hipLaunchKernelGGL((k_apply_pair<true, 4, 2, 1, true>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, (unsigned long long *)nullptr, d_order);
   });
+  for (unsigned step : {24u, 32u, 40u, 48u, 64u}) {
+    char nm[96];
+    snprintf(nm, sizeof nm, "C2 apply_pair alone, balanced, priority by entries remaining, step %u", step);
+    run(nm, true, [&] {
+      hipLaunchKernelGGL((k_apply_pair<true, 4, 2, 2, true>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, (unsigned long long *)nullptr, d_order, step);
+    });
+  }
   run("C2 apply_pair alone, shipped (again)", true, [&] {
     hipLaunchKernelGGL((k_apply_pair<true, 4, 2, 1, true>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, (unsigned long long *)nullptr);
   });
