@@ -995,3 +995,55 @@ def test_raw_frames_in_a_later_round(torch_cuda, ch):
     enc = glc_amd.Encoder(sr).encode(x, ch)
     assert enc.to_bytes() == glc_amd.EncodedAudio.from_records(sr, x.size, ch, recs).to_bytes()
     assert enc.info().n_raw_frames == int(split_records(recs, ch)[0].sum())
+
+
+@pytest.mark.parametrize("ch,shape", [(2, "sparse-then-dense"), (2, "dense-then-sparse"), (1, "raw-then-tonal"),
+                                       (3, "sparse-then-dense"), (2, "three-rounds-raw-last")])
+def test_host_encode_pipeline_across_density_changes(torch_cuda, ch, shape):
+    """glc_encode runs upload / kernels / download as a pipeline over rounds and grows the EncodedAudio's
+    pools ahead of need from the density of the rounds it has seen: streams whose later rounds are much
+    denser (the estimate is too small), much sparser (the pools shrink at the end), or raw (the other
+    pool) must give exactly the bytes of the unpipelined device path - one frames_from_device_records over
+    the whole range - and, on a window across the first round boundary, the oracle's records."""
+    sr = 48000
+    first = (4096 + ch - 1) // ch            # frames of the first round (csrc/glc_api.hip)
+    rounds = 3 if shape.startswith("three") else 2
+    nf = first + 4096 * (rounds - 1) - 37    # ragged last round
+    rng = np.random.default_rng(1234 + ch + len(shape))
+    total = nf * 1024
+
+    def tones(n, a, b):  # rows [a, b) of an n-tone chord per channel
+        t = np.arange(a, b, dtype=np.float64)[:, None]
+        out = np.zeros((b - a, ch), np.float32)
+        for i in range(n):
+            out += (np.sin(2 * np.pi * rng.uniform(60, 15000, (1, ch)) * t / sr + i) * (0.5 / n)).astype(np.float32)
+        return out
+
+    cut = first * 1024
+    x = np.empty((total, ch), np.float32)
+    if shape == "sparse-then-dense":
+        x[:cut], x[cut:] = tones(2, 0, cut), tones(40, cut, total)
+    elif shape == "dense-then-sparse":
+        x[:cut], x[cut:] = tones(40, 0, cut), tones(1, cut, total) * 0.2
+    elif shape == "raw-then-tonal":
+        x[:cut], x[cut:] = rng.standard_normal((cut, ch)).astype(np.float32) * 0.3, tones(8, cut, total)
+    else:
+        c2 = (first + 4096) * 1024
+        x[:c2], x[c2:] = tones(6, 0, c2), rng.standard_normal((total - c2, ch)).astype(np.float32) * 0.3
+    x = np.ascontiguousarray(x, np.float32).reshape(-1)
+    plan = glc_amd.plan_encode(x.size, ch)
+    assert plan.n_frames == nf
+    enc = glc_amd.Encoder(sr)
+    got = enc.encode(x, ch)
+    recs, _ = device_encode(torch_cuda, x, sr, ch, want_coeffs=False)
+    assert got.to_bytes() == glc_amd.EncodedAudio.from_records(sr, x.size, ch, recs).to_bytes()
+    # twice through the same context: the second call reuses every buffer, event and stream of the first
+    assert enc.encode(x, ch).to_bytes() == got.to_bytes()
+    rec = glc_amd.lib.glc_record_bytes(ch)
+    f0, f1 = first - 12, first + 12
+    t0, t1 = f0 * 1024 - 512, (f1 - 1) * 1024 - 512 + 2048
+    want, _ = O.encode_range_records(x[t0 * ch:t1 * ch], t0, t1 - t0, x.size, sr, ch, f0, f1)
+    assert np.array_equal(recs[f0 * rec:f1 * rec], want)
+    info = got.info()
+    if "raw" in shape:
+        assert 0 < info.n_raw_frames < nf
