@@ -15,8 +15,8 @@ extern "C" {
 /* Which inverse-transform kernel the decode entry points of `ctx` launch (imdct_block,
  * src/codec.rs:377-390):
  *   0  shipped: k_imdct_plan + k_imdct_apply - 8 frames of one channel per unit over the union of
- *      their indices; union records in global memory, coefficients fed from SGPRs, absent row pairs
- *      skipped by scalar branches
+ *      their indices; union records in global memory, coefficients fed from SGPRs, absent rows
+ *      skipped one by one by scalar branches
  *   1  k_imdct_rows: one row per workgroup, no grouping (the simplest restatement)
  *   2  plan + apply without the skip (every row takes every union entry)
  *   3  plan + apply without the issue-priority schedule (waves of a SIMD finish one after the other)

@@ -4,6 +4,8 @@
 // Build: make -C gapless-lossy-codec_amd/csrc tools      Usage: build/decode_breakdown [variants, e.g. 0,4,0,4] [reps = 100]
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -81,6 +83,23 @@ int main(int argc, char **argv) {
     for (int i = 0; i < reps; ++i) GL(glc_decode_device(dec, F, d_out, (frames + 1) * 1024 * ch, nullptr, nullptr));
     GL(glc_ctx_timer_end(dec, &ms));
     std::printf("glc_decode_device (D1 + D2), rows resident: %7.1f us per call\n", ms / reps * 1e3);
+  }
+  {  // host boundary: Decoder::decode from an EncodedAudio in host memory to PCM in host memory
+    std::vector<float> out((frames + 1) * 1024 * ch);
+    uint64_t n_out = 0;
+    double best = 1e30, first = 0;
+    glc_ctx *hd = nullptr;
+    GL(glc_ctx_create(0, 48000, &hd));
+    for (int i = 0; i < 12; ++i) {
+      const auto t0 = std::chrono::steady_clock::now();
+      GL(glc_decode(hd, F, out.data(), out.size(), &n_out));
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (i == 0) first = ms;
+      else best = std::min(best, ms);
+    }
+    std::printf("glc_decode, EncodedAudio in host memory -> %llu samples in host memory: first call %.3f ms (row preparation + upload), then %.3f ms\n",
+                static_cast<unsigned long long>(n_out), first, best);
+    glc_ctx_destroy(hd);
   }
   glc_frames_free(F);
   OK(hipFree(d_blk));
