@@ -65,7 +65,7 @@ def chord(np, t0, t_count):
     return x.astype(np.float32).reshape(-1)
 
 
-SPINUP_STEPS = 150  # untimed, before the --warmup steps
+SPINUP_STEPS = 500  # untimed, before the --warmup steps
 DECODE_SPINUP_CALLS = 400  # untimed decode calls before the decode leg is timed
 
 

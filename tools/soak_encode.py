@@ -1,7 +1,9 @@
 """End-to-end soak against the CPU oracle (checker only): seeded random configurations (sample rate,
 channels, ragged lengths, content mix from silence to clipping noise) through Encoder::encode and
-Decoder::decode; `.glc` bytes and decoded PCM bits must equal the oracle's every time.
-Usage: python tools/soak_encode.py [cases]"""
+Decoder::decode; `.glc` bytes and decoded PCM bits must equal the oracle's every time.  With the word
+`pipeline` every case is a many-channel stream of two to four encode rounds, so that glc_encode runs
+as its three-thread pipeline (one round runs on the calling thread alone).
+Usage: python tools/soak_encode.py [cases] [pipeline]"""
 import os
 import sys
 import time
@@ -14,6 +16,7 @@ import glc_amd  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+pipeline = len(sys.argv) > 2 and sys.argv[2] == "pipeline"
 rates = [8000, 11025, 16000, 22050, 32000, 44100, 48000, 88200, 96000, 176400, 192000, 12345]
 encs, decs = {}, {}
 bad = 0
@@ -23,9 +26,14 @@ for case in range(cases):
     sr = int(rng.choice(rates))
     ch = int(rng.choice([1, 1, 2, 2, 2, 3, 4, 5, 6, 8]))
     n_per = int(rng.integers(513, 30000)) if rng.random() < 0.9 else int(rng.integers(30000, 600000))
+    if pipeline:  # first round = ceil(4096 / ch) frames, later rounds 4096: 2 .. 4 rounds
+        ch = int(rng.choice([8, 12, 16, 24]))
+        first = -(-4096 // ch)
+        frames = 2 * first + int(rng.integers(1, 300)) if rng.random() < 0.8 else first + 4096 + int(rng.integers(1, 600))
+        n_per = frames * 1024 - int(rng.integers(0, 1024))
     n = max(n_per * ch - int(rng.integers(0, ch)), 513 * ch)
     t = np.arange(n_per + 1, dtype=np.float64)[:, None]
-    kind = int(rng.integers(0, 6))
+    kind = int(rng.integers(0, 5 if pipeline else 6))  # kind 5 is too costly to generate at pipeline sizes
     if kind == 0:
         x = np.sin(2 * np.pi * rng.uniform(30, sr / 2.2, (1, ch)) * t / sr) * 0.5
     elif kind == 1:
@@ -66,7 +74,7 @@ for case in range(cases):
     if not ok:
         bad += 1
         print(f"case {case}: MISMATCH sr={sr} ch={ch} n={n} kind={kind} amp={amp}", flush=True)
-    if case % 50 == 49 or case == cases - 1:
+    if case % (5 if pipeline else 50) == (4 if pipeline else 49) or case == cases - 1:
         print(f"encode soak case {case + 1}: {bad} mismatching cases so far, {globals().get('panics', 0)} inputs refused by both "
               f"({time.time() - t0:.0f} s)", flush=True)
 sys.exit(1 if bad else 0)
