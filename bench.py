@@ -299,6 +299,10 @@ def main():
     if rank == 0 and world == 1:
         best = None
         ea_h = blob = None
+        for _ in range(60):  # the device clocked down while the records came back to the host: 75 ms of the same call
+            ea_h = enc.encode(pcm_host, CH)
+            del ea_h
+        ea_h = None
         for _ in range(8):
             # the previous result is dropped first, as a caller encoding file after file would: with two
             # EncodedAudio alive the allocator hands out fresh pages and the call pays their page faults
