@@ -83,9 +83,10 @@ struct glc_ctx {
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;  // glc_ctx_timer_*
   hipStream_t copy_stream = nullptr;  // glc_encode: uploads run ahead of the kernels on this one
   hipEvent_t ev_copy = nullptr;
-  hipStream_t down_stream = nullptr;  // glc_encode: round i is compacted and its metadata comes down while round i+1 is transformed
-  hipStream_t pay_stream = nullptr;   // glc_encode: ... and the blob itself, fetched by the collecting thread
-  std::vector<hipEvent_t> ev_round;   // three per round: samples uploaded, records written, blob compacted
+  hipStream_t stream_b = nullptr;     // glc_encode: odd rounds are transformed here, beside the even ones on `stream`
+  DevBuf coef_b;                      // ... with a coefficient workspace of their own
+  hipStream_t down_stream = nullptr;  // glc_encode: round i is compacted and its blob comes down while round i+1 is transformed
+  std::vector<hipEvent_t> ev_round;   // two per round: samples uploaded, records written
   glc::HostTables host;
   glc::DeviceTables dev{};
   DevBuf tables;     // all constant tables in one allocation
@@ -269,8 +270,9 @@ void glc_ctx_destroy(glc_ctx *ctx) {
   ctx->stream_out.release();
   for (hipEvent_t e : ctx->ev_round)
     if (e) (void)hipEventDestroy(e);
+  if (ctx->stream_b) (void)hipStreamDestroy(ctx->stream_b);
+  ctx->coef_b.release();
   if (ctx->down_stream) (void)hipStreamDestroy(ctx->down_stream);
-  if (ctx->pay_stream) (void)hipStreamDestroy(ctx->pay_stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   ctx->tables.release();
@@ -337,9 +339,11 @@ int glc_ctx_tables(const glc_ctx *ctx, float *cos_table, float *window, float *n
 
 // ------------------------------------------------------------------------------ encode
 
-int glc_encode_range_device(glc_ctx *ctx, const float *d_pcm, uint64_t t0, uint64_t t_count,
-                            uint64_t n_samples, uint16_t channels, uint64_t frame_begin,
-                            uint64_t frame_end, void *d_records, float *d_coeffs) {
+// glc_encode_range_device on a given stream with a given coefficient workspace (glc_encode runs
+// alternate rounds on two streams)
+static int encode_range_on(glc_ctx *ctx, hipStream_t stream, DevBuf &coef_ws, const float *d_pcm, uint64_t t0, uint64_t t_count,
+                           uint64_t n_samples, uint16_t channels, uint64_t frame_begin, uint64_t frame_end,
+                           void *d_records, float *d_coeffs) {
   if (!ctx || !d_pcm || !d_records) return fail(ctx, GLC_EINVAL, "glc_encode_range_device: null argument");
   const glc_plan plan = glc::plan_encode(n_samples, channels);
   if (plan.n_frames == 0)
@@ -366,19 +370,27 @@ int glc_encode_range_device(glc_ctx *ctx, const float *d_pcm, uint64_t t0, uint6
   const uint64_t chunk = d_coeffs ? (frame_end - frame_begin ? frame_end - frame_begin : 1) : kEncodeChunkFrames;
   if (!d_coeffs) {
     const uint64_t rows = std::min<uint64_t>(chunk, frame_end - frame_begin) * ch;
-    GLC_HIP(ctx, ctx->coef.reserve(std::max<size_t>(rows, 1) * glc::kHop * sizeof(float)));
+    GLC_HIP(ctx, coef_ws.reserve(std::max<size_t>(rows, 1) * glc::kHop * sizeof(float)));
   }
   for (uint64_t f = frame_begin; f < frame_end; f += chunk) {
     const uint64_t nf = std::min<uint64_t>(chunk, frame_end - f);
     const uint32_t M = static_cast<uint32_t>(nf * ch);
-    float *coef = d_coeffs ? d_coeffs + (f - frame_begin) * ch * glc::kHop : static_cast<float *>(ctx->coef.p);
+    float *coef = d_coeffs ? d_coeffs + (f - frame_begin) * ch * glc::kHop : static_cast<float *>(coef_ws.p);
     uint8_t *r = recs + (f - frame_begin) * rec;
-    GLC_HIP(ctx, glc::launch_mdct_forward(ctx->dev, view, f, M, coef, ctx->stream));
+    GLC_HIP(ctx, glc::launch_mdct_forward(ctx->dev, view, f, M, coef, stream));
     bool decided = false;
-    GLC_HIP(ctx, glc::launch_quantize(ctx->dev, coef, M, ch, view, f, r, ctx->stream, &decided));
-    if (!decided) GLC_HIP(ctx, glc::launch_decide_raw(ctx->dev, view, f, static_cast<uint32_t>(nf), r, ctx->stream));
+    GLC_HIP(ctx, glc::launch_quantize(ctx->dev, coef, M, ch, view, f, r, stream, &decided));
+    if (!decided) GLC_HIP(ctx, glc::launch_decide_raw(ctx->dev, view, f, static_cast<uint32_t>(nf), r, stream));
   }
   return GLC_OK;
+}
+
+int glc_encode_range_device(glc_ctx *ctx, const float *d_pcm, uint64_t t0, uint64_t t_count,
+                            uint64_t n_samples, uint16_t channels, uint64_t frame_begin,
+                            uint64_t frame_end, void *d_records, float *d_coeffs) {
+  if (!ctx) return GLC_EINVAL;
+  return encode_range_on(ctx, ctx->stream, ctx->coef, d_pcm, t0, t_count, n_samples, channels, frame_begin, frame_end,
+                         d_records, d_coeffs);
 }
 
 int glc_mdct_forward_device(glc_ctx *ctx, const float *d_pcm, uint64_t t0, uint64_t t_count,
@@ -534,19 +546,28 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
   // its own host thread, because two of the stages block their caller: a copy from or to pageable
   // memory returns when it is done.
   //   uploader thread   round i+1's samples go up, back to back                      (copy_stream)
-  //   launcher thread   round i is transformed and quantised as soon as it is up     (the context's stream)
-  //                     ... and compacted beside the next round's transform          (down_stream)
-  //   this thread       round i-1's blob comes down: metadata, then the payload straight into the
-  //                     EncodedAudio's pools, and is indexed                         (pay_stream)
+  //   launcher thread   round i is transformed and quantised as soon as it is up     (stream / stream_b)
+  //   this thread       round i-1 is compacted, its blob comes down - metadata, then the payload
+  //                     straight into the EncodedAudio's pools - and is indexed       (down_stream)
   // PCIe is full duplex and the compaction kernels are small, so a call costs
   // max(upload, kernels) + the first upload + the last round's compaction and download instead of
-  // their sum.  Copies are issued only when their data is ready (never queued behind an unfinished
-  // dependency: the copy engines execute in submission order).  The first round is the one whose
-  // upload nothing hides, so it is kept as small as the transform stays efficient at: 4096 rows (the
-  // LDS-DMA kernel's threshold; it runs at 87 % of its full-batch rate there).  BASELINE config 2
-  // (4096 stereo frames) becomes two rounds; a stream of one round runs on this thread alone.
-  const uint64_t first_round = std::min<uint64_t>(kEncodeChunkFrames, (4096 + ch - 1) / ch);
-  const bool split_first = plan.n_frames >= 2 * first_round;
+  // their sum.  One rule keeps the stages from blocking each other: NOTHING IS QUEUED BEHIND AN
+  // UNFINISHED DEPENDENCY.  A process has a handful of hardware queues for all its streams, and a
+  // queue is in order: a `hipStreamWaitEvent` that has to wait parks every stream that shares its
+  // queue (seen in the trace: the compaction's wait for the quantiser held the NEXT upload's event
+  // back, and with it the next transform), and the copy engines execute in submission order.  So a
+  // stage waits on the host (thread hand-off, hipEventSynchronize) and only then queues its work.
+  // Rounds: the upload nothing hides is the first round's, and the kernels nothing hides are the last
+  // round's, so a stream opens with four rounds of 2048 rows (0.15 ms of PCIe each for stereo) before
+  // it goes on in rounds of kEncodeChunkFrames.  A 2048-row launch alone leaves the chip half empty
+  // (its time is one workgroup's 2048-step chain, 0.22 ms whatever the row count), so consecutive
+  // rounds run on TWO streams with a coefficient workspace each: the next round's transform fills in
+  // beside this one's, and a round's quantiser runs beside the next transform (four 1024-frame stereo
+  // launches: 0.87 ms on one stream, 0.67 ms alternating, 0.59 ms as one launch; two 2048-frame ones
+  // 0.66 / 0.60).  BASELINE config 2 (4096 stereo frames) is the four opening rounds; a stream of
+  // one round runs on this thread alone.
+  const uint64_t piece = std::max<uint64_t>(1, (2048 + ch - 1) / ch);  // frames of an opening round
+  const uint64_t opening = 4 * piece;
   struct Round {
     uint64_t f0, nf, blob_off, hi;  // hi: interleaved samples that must be on the device before its kernels run
     glc::CompactLayout l;
@@ -557,7 +578,9 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
   try {
     uint64_t blob_off = 0;
     for (uint64_t f = 0, nf = 0; f < plan.n_frames; f += nf) {
-      nf = std::min<uint64_t>(f == 0 && split_first ? first_round : kEncodeChunkFrames, plan.n_frames - f);
+      const uint64_t left = plan.n_frames - f;
+      nf = std::min<uint64_t>(f < opening ? piece : kEncodeChunkFrames, left);
+      if (left - nf < piece / 2) nf = left;  // no round for a remainder of less than half a piece
       // frames [f, f+nf) read per-channel samples below 1024*(f+nf-1) - 512 + 2048
       const uint64_t hi_t = std::min<uint64_t>(t_count, (f + nf - 1) * glc::kHop + glc::kFrame - glc::kHop / 2);
       Round r{f, nf, blob_off, std::min<uint64_t>(n_samples, hi_t * ch), glc::compact_layout(ch, nf)};
@@ -590,11 +613,12 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
   GLC_HIP(ctx, ctx->host_stage.reserve(meta_cap));
   // the per-round workspaces at their largest now: growing one mid-pipeline would free it under queued work
   GLC_HIP(ctx, ctx->coef.reserve(static_cast<size_t>(max_nf) * ch * glc::kHop * sizeof(float)));
+  if (n_rounds > 1) GLC_HIP(ctx, ctx->coef_b.reserve(static_cast<size_t>(max_nf) * ch * glc::kHop * sizeof(float)));
   GLC_HIP(ctx, ctx->pack_meta.reserve(compact_scratch_bytes(max_nf * ch)));
+  if (!ctx->stream_b) GLC_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_b, hipStreamNonBlocking));
   if (!ctx->copy_stream) GLC_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
   if (!ctx->down_stream) GLC_HIP(ctx, hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
-  if (!ctx->pay_stream) GLC_HIP(ctx, hipStreamCreateWithFlags(&ctx->pay_stream, hipStreamNonBlocking));
-  while (ctx->ev_round.size() < 3 * n_rounds) {
+  while (ctx->ev_round.size() < 2 * n_rounds) {
     hipEvent_t e = nullptr;
     GLC_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     try {
@@ -608,13 +632,13 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
   float *d_pcm = static_cast<float *>(ctx->pcm.p);
   uint8_t *d_blob = static_cast<uint8_t *>(ctx->pack_blob.p);
   uint8_t *h_meta = static_cast<uint8_t *>(ctx->host_stage.p);
-  hipEvent_t *ev_up = ctx->ev_round.data(), *ev_rec = ev_up + n_rounds, *ev_blob = ev_rec + n_rounds;
+  hipEvent_t *ev_up = ctx->ev_round.data(), *ev_rec = ev_up + n_rounds;
 
   // progress shared by the three threads; an error anywhere stops all of them
   struct Progress {
     std::mutex mu;
     std::condition_variable cv;
-    size_t uploaded = 0, queued = 0;  // rounds whose upload event / blob event has been recorded
+    size_t uploaded = 0, queued = 0;  // rounds whose upload event / records event has been recorded
     int rc = GLC_OK;
     std::string msg;
     void set_error(int code, const std::string &m) {
@@ -656,18 +680,14 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
     for (size_t i = 0; i < n_rounds; ++i) {
       const Round &r = rounds[i];
       if (!prog.wait_for(prog.uploaded, i)) return;
-      hipError_t e = hipStreamWaitEvent(ctx->stream, ev_up[i], 0);
+      hipStream_t cs = (i & 1) ? ctx->stream_b : ctx->stream;
+      hipError_t e = hipStreamWaitEvent(cs, ev_up[i], 0);
       if (e != hipSuccess) return prog.set_error(GLC_EHIP, hip_msg("glc_encode: queueing a round", e));
       uint8_t *recs = static_cast<uint8_t *>(ctx->records.p) + r.f0 * rec;
-      int rc = glc_encode_range_device(ctx, d_pcm, 0, t_count, n_samples, channels, r.f0, r.f0 + r.nf, recs, nullptr);
-      if (rc == GLC_OK) {
-        e = hipEventRecord(ev_rec[i], ctx->stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->down_stream, ev_rec[i], 0);
-        if (e != hipSuccess) return prog.set_error(GLC_EHIP, hip_msg("glc_encode: queueing a round", e));
-        rc = compact_launch(ctx, recs, r.nf, ch, d_blob + r.blob_off, ctx->down_stream);
-      }
+      int rc = encode_range_on(ctx, cs, (i & 1) ? ctx->coef_b : ctx->coef, d_pcm, 0, t_count, n_samples, channels, r.f0,
+                               r.f0 + r.nf, recs, nullptr);
       if (rc != GLC_OK) return prog.set_error(rc, ctx->err);
-      e = hipEventRecord(ev_blob[i], ctx->down_stream);
+      e = hipEventRecord(ev_rec[i], cs);
       if (e != hipSuccess) return prog.set_error(GLC_EHIP, hip_msg("glc_encode: queueing a round", e));
       prog.advance(prog.queued);
     }
@@ -684,10 +704,16 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
         if (F->pairs.size() < want) F->pairs.resize(want);
       }
       if (!prog.wait_for(prog.queued, i)) return;
-      hipError_t e = hipEventSynchronize(ev_blob[i]);
+      hipError_t e = hipEventSynchronize(ev_rec[i]);  // the round's records are written: compact them now
+      if (e != hipSuccess) return prog.set_error(GLC_EHIP, hip_msg("glc_encode: waiting for a round", e));
+      {
+        uint8_t *recs = static_cast<uint8_t *>(ctx->records.p) + r.f0 * rec;
+        const int crc = compact_launch(ctx, recs, r.nf, ch, d_blob + r.blob_off, ctx->down_stream);
+        if (crc != GLC_OK) return prog.set_error(crc, "glc_encode: compaction launch failed");
+      }
       // header + raw flags + scale factors + list lengths: they say how long the payload is
-      if (e == hipSuccess) e = hipMemcpyAsync(h_meta, d_blob + r.blob_off, r.l.o_pairs, hipMemcpyDeviceToHost, ctx->pay_stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(ctx->pay_stream);
+      e = hipMemcpyAsync(h_meta, d_blob + r.blob_off, r.l.o_pairs, hipMemcpyDeviceToHost, ctx->down_stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->down_stream);
       if (e != hipSuccess) return prog.set_error(GLC_EHIP, hip_msg("glc_encode: download", e));
       glc::CompactHeader h;
       std::memcpy(&h, h_meta, sizeof h);
@@ -705,15 +731,15 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
       if (F->raw.size() < r_at + h.n_raw_rows * glc::kFrame) F->raw.resize(r_at + h.n_raw_rows * glc::kFrame);
       p_used += h.n_pairs;
       r_used += h.n_raw_rows * glc::kFrame;
-      if (h.n_pairs) e = hipMemcpyAsync(F->pairs.data() + p_at, blob + r.l.o_pairs, h.n_pairs * 4, hipMemcpyDeviceToHost, ctx->pay_stream);
+      if (h.n_pairs) e = hipMemcpyAsync(F->pairs.data() + p_at, blob + r.l.o_pairs, h.n_pairs * 4, hipMemcpyDeviceToHost, ctx->down_stream);
       if (e == hipSuccess && h.n_raw_rows)
         e = hipMemcpyAsync(F->raw.data() + r_at, blob + glc::compact_raw_offset(r.l, h.n_pairs), h.n_raw_rows * glc::kFrame * 2,
-                           hipMemcpyDeviceToHost, ctx->pay_stream);
+                           hipMemcpyDeviceToHost, ctx->down_stream);
       bool canonical = true;
       int rc = GLC_OK;
       if (e == hipSuccess) rc = glc::index_compact_meta(F.get(), ch, h, h_meta, r.f0, p_at, r_at, /*trusted=*/true, &canonical);
       // the pools may move when the next round grows them, and h_meta is reused: all of it has to have landed
-      const hipError_t e2 = hipStreamSynchronize(ctx->pay_stream);
+      const hipError_t e2 = hipStreamSynchronize(ctx->down_stream);
       if (e == hipSuccess) e = e2;
       if (e != hipSuccess) return prog.set_error(GLC_EHIP, hip_msg("glc_encode: download", e));
       if (rc != GLC_OK) return prog.set_error(rc, std::string("glc_encode: ") + glc_last_error(nullptr));
@@ -757,8 +783,8 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
     // nothing may still be in flight into the caller's or the result's memory when this returns
     (void)hipStreamSynchronize(ctx->copy_stream);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream_b);
     (void)hipStreamSynchronize(ctx->down_stream);
-    (void)hipStreamSynchronize(ctx->pay_stream);
     return fail(ctx, rc, msg);
   }
   try {

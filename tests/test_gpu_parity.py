@@ -1004,9 +1004,10 @@ def test_host_encode_pipeline_across_density_changes(torch_cuda, ch, shape):
     pools ahead of need from the density of the rounds it has seen: streams whose later rounds are much
     denser (the estimate is too small), much sparser (the pools shrink at the end), or raw (the other
     pool) must give exactly the bytes of the unpipelined device path - one frames_from_device_records over
-    the whole range - and, on a window across the first round boundary, the oracle's records."""
+    the whole range - and, on windows across round boundaries, the oracle's records."""
     sr = 48000
-    first = (4096 + ch - 1) // ch            # frames of the first round (csrc/glc_api.hip)
+    piece = (2048 + ch - 1) // ch            # frames of an opening round; four of them, then 4096 (csrc/glc_api.hip)
+    first = 4 * piece
     rounds = 3 if shape.startswith("three") else 2
     nf = first + 4096 * (rounds - 1) - 37    # ragged last round
     rng = np.random.default_rng(1234 + ch + len(shape))
@@ -1040,10 +1041,11 @@ def test_host_encode_pipeline_across_density_changes(torch_cuda, ch, shape):
     # twice through the same context: the second call reuses every buffer, event and stream of the first
     assert enc.encode(x, ch).to_bytes() == got.to_bytes()
     rec = glc_amd.lib.glc_record_bytes(ch)
-    f0, f1 = first - 12, first + 12
-    t0, t1 = f0 * 1024 - 512, (f1 - 1) * 1024 - 512 + 2048
-    want, _ = O.encode_range_records(x[t0 * ch:t1 * ch], t0, t1 - t0, x.size, sr, ch, f0, f1)
-    assert np.array_equal(recs[f0 * rec:f1 * rec], want)
+    for edge in (piece, first):              # across a boundary between opening rounds, and into the first long round
+        f0, f1 = edge - 12, edge + 12
+        t0, t1 = f0 * 1024 - 512, (f1 - 1) * 1024 - 512 + 2048
+        want, _ = O.encode_range_records(x[t0 * ch:t1 * ch], t0, t1 - t0, x.size, sr, ch, f0, f1)
+        assert np.array_equal(recs[f0 * rec:f1 * rec], want)
     info = got.info()
     if "raw" in shape:
         assert 0 < info.n_raw_frames < nf
