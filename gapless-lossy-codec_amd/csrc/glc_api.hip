@@ -7,7 +7,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <memory>
 #include <mutex>
@@ -75,6 +77,52 @@ struct HostBuf {
   }
 };
 
+// A parked host thread that runs one job at a time (glc_encode's uploader and launcher): started on
+// first use and kept for the life of the context, because a fresh std::thread costs ~50 us before its
+// first HIP call returns (thread start + the runtime's per-thread state) - 5 % of a config-2 call.
+struct Worker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool has_job = false, idle = true, quit = false;
+  void submit(std::function<void()> j) {  // may throw std::system_error / std::bad_alloc on first use
+    if (!th.joinable())
+      th = std::thread([this] {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+          cv.wait(lk, [&] { return has_job || quit; });
+          if (quit) return;
+          std::function<void()> j2 = std::move(job);
+          has_job = false;
+          lk.unlock();
+          j2();  // jobs do not throw (glc_encode wraps them)
+          lk.lock();
+          idle = true;
+          cv.notify_all();
+        }
+      });
+    std::lock_guard<std::mutex> lk(mu);
+    job = std::move(j);
+    has_job = true;
+    idle = false;
+    cv.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return idle; });
+  }
+  ~Worker() {
+    if (!th.joinable()) return;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+      cv.notify_all();
+    }
+    th.join();
+  }
+};
+
 struct glc_ctx {
   int device = 0;
   uint32_t sample_rate = 0;
@@ -86,7 +134,8 @@ struct glc_ctx {
   hipStream_t stream_b = nullptr;     // glc_encode: odd rounds are transformed here, beside the even ones on `stream`
   DevBuf coef_b;                      // ... with a coefficient workspace of their own
   hipStream_t down_stream = nullptr;  // glc_encode: round i is compacted and its blob comes down while round i+1 is transformed
-  std::vector<hipEvent_t> ev_round;   // two per round: samples uploaded, records written
+  std::vector<hipEvent_t> ev_round;   // one per round: records written
+  std::unique_ptr<Worker> enc_up, enc_launch;  // glc_encode's helper threads (multi-round streams only)
   glc::HostTables host;
   glc::DeviceTables dev{};
   DevBuf tables;     // all constant tables in one allocation
@@ -261,6 +310,8 @@ int glc_ctx_create(int device, uint32_t sample_rate, glc_ctx **out) {
 void glc_ctx_destroy(glc_ctx *ctx) {
   if (!ctx) return;
   DeviceGuard guard(ctx->device);
+  ctx->enc_up.reset();      // joins the helper threads (idle: glc_encode waits for them before it returns)
+  ctx->enc_launch.reset();
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
   if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
@@ -419,6 +470,7 @@ static size_t compact_scratch_bytes(uint64_t M) {
 
 static int compact_launch(glc_ctx *ctx, const void *d_records, uint64_t n_frames, uint32_t ch, void *d_blob,
                           hipStream_t stream) {
+  DevBuf &pm = ctx->pack_meta;
   const uint64_t M64 = n_frames * ch;
   if (M64 > 0xFFFFFFFFull) return fail(ctx, GLC_EINVAL, "compaction: frame range too long");
   const uint32_t M = static_cast<uint32_t>(M64);
@@ -432,8 +484,8 @@ static int compact_launch(glc_ctx *ctx, const void *d_records, uint64_t n_frames
   };
   const size_t o_loc = place(static_cast<size_t>(M) * 4), o_blk = place(nblk * 8), o_blkr = place(nblk * 8);
   const size_t o_tot = place(16);
-  GLC_HIP(ctx, ctx->pack_meta.reserve(std::max<size_t>(off, compact_scratch_bytes(M))));
-  uint8_t *mb = static_cast<uint8_t *>(ctx->pack_meta.p);
+  GLC_HIP(ctx, pm.reserve(std::max<size_t>(off, compact_scratch_bytes(M))));
+  uint8_t *mb = static_cast<uint8_t *>(pm.p);
   uint8_t *blob = static_cast<uint8_t *>(d_blob);
   GLC_HIP(ctx, hipMemsetAsync(blob, 0, l.o_pairs, stream));  // header + section padding: deterministic bytes
   GLC_HIP(ctx, glc::launch_compact(static_cast<const uint8_t *>(d_records), M, ch, n_frames,
@@ -606,11 +658,13 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
     return fail(ctx, GLC_ENOMEM, "glc_encode: host allocation failed");
   }
   const size_t n_rounds = rounds.size();
-  const size_t meta_cap = align_up(glc::compact_layout(ch, max_nf).o_pairs, 256);
+  // pinned landing zone of a round's blob: metadata + its expected pairs (at most the whole blob, at most 64 MiB)
+  const size_t stage_cap = std::max<size_t>(std::min<size_t>(align_up(glc::compact_layout(ch, max_nf).bound, 256), size_t(64) << 20),
+                                            align_up(glc::compact_layout(ch, max_nf).o_pairs, 256));
   GLC_HIP(ctx, ctx->pcm.reserve(static_cast<size_t>(t_count) * ch * sizeof(float)));
   GLC_HIP(ctx, ctx->records.reserve(static_cast<size_t>(plan.n_frames) * rec));
   GLC_HIP(ctx, ctx->pack_blob.reserve(rounds.back().blob_off + align_up(rounds.back().l.bound, 256)));
-  GLC_HIP(ctx, ctx->host_stage.reserve(meta_cap));
+  GLC_HIP(ctx, ctx->host_stage.reserve(stage_cap));
   // the per-round workspaces at their largest now: growing one mid-pipeline would free it under queued work
   GLC_HIP(ctx, ctx->coef.reserve(static_cast<size_t>(max_nf) * ch * glc::kHop * sizeof(float)));
   if (n_rounds > 1) GLC_HIP(ctx, ctx->coef_b.reserve(static_cast<size_t>(max_nf) * ch * glc::kHop * sizeof(float)));
@@ -618,7 +672,7 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
   if (!ctx->stream_b) GLC_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_b, hipStreamNonBlocking));
   if (!ctx->copy_stream) GLC_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
   if (!ctx->down_stream) GLC_HIP(ctx, hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
-  while (ctx->ev_round.size() < 2 * n_rounds) {
+  while (ctx->ev_round.size() < n_rounds) {
     hipEvent_t e = nullptr;
     GLC_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     try {
@@ -632,13 +686,13 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
   float *d_pcm = static_cast<float *>(ctx->pcm.p);
   uint8_t *d_blob = static_cast<uint8_t *>(ctx->pack_blob.p);
   uint8_t *h_meta = static_cast<uint8_t *>(ctx->host_stage.p);
-  hipEvent_t *ev_up = ctx->ev_round.data(), *ev_rec = ev_up + n_rounds;
+  hipEvent_t *ev_rec = ctx->ev_round.data();
 
   // progress shared by the three threads; an error anywhere stops all of them
   struct Progress {
     std::mutex mu;
     std::condition_variable cv;
-    size_t uploaded = 0, queued = 0;  // rounds whose upload event / records event has been recorded
+    size_t uploaded = 0, queued = 0;  // rounds whose samples are on the device / whose records event has been recorded
     int rc = GLC_OK;
     std::string msg;
     void set_error(int code, const std::string &m) {
@@ -659,6 +713,7 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
     }
   } prog;
   auto hip_msg = [](const char *what, hipError_t e) { return std::string(what) + ": " + hipGetErrorString(e); };
+  std::atomic<double> pairs_per_frame{0.0};  // stored pairs per frame so far, + 25 % (sizes the next round's first copy)
 
   auto upload = [&] {  // stage 1
     DeviceGuard g(ctx->device);
@@ -669,7 +724,9 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
       if (r.hi > copied)
         e = hipMemcpyAsync(d_pcm + copied, pcm + copied, (r.hi - copied) * sizeof(float), hipMemcpyHostToDevice, ctx->copy_stream);
       copied = std::max(copied, r.hi);
-      if (e == hipSuccess) e = hipEventRecord(ev_up[i], ctx->copy_stream);
+      // a copy from pageable memory has completed when the call returns; should the runtime ever
+      // queue it instead, this is where it is waited for (the launcher queues nothing behind it)
+      if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
       if (e != hipSuccess) return prog.set_error(e == hipErrorOutOfMemory ? GLC_ENOMEM : GLC_EHIP, hip_msg("glc_encode: upload", e));
       prog.advance(prog.uploaded);
       { std::lock_guard<std::mutex> lk(prog.mu); if (prog.rc != GLC_OK) return; }
@@ -681,8 +738,7 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
       const Round &r = rounds[i];
       if (!prog.wait_for(prog.uploaded, i)) return;
       hipStream_t cs = (i & 1) ? ctx->stream_b : ctx->stream;
-      hipError_t e = hipStreamWaitEvent(cs, ev_up[i], 0);
-      if (e != hipSuccess) return prog.set_error(GLC_EHIP, hip_msg("glc_encode: queueing a round", e));
+      hipError_t e = hipSuccess;
       uint8_t *recs = static_cast<uint8_t *>(ctx->records.p) + r.f0 * rec;
       int rc = encode_range_on(ctx, cs, (i & 1) ? ctx->coef_b : ctx->coef, d_pcm, 0, t_count, n_samples, channels, r.f0,
                                r.f0 + r.nf, recs, nullptr);
@@ -706,21 +762,34 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
       if (!prog.wait_for(prog.queued, i)) return;
       hipError_t e = hipEventSynchronize(ev_rec[i]);  // the round's records are written: compact them now
       if (e != hipSuccess) return prog.set_error(GLC_EHIP, hip_msg("glc_encode: waiting for a round", e));
+      const uint8_t *blob = d_blob + r.blob_off;
+      uint8_t *hm = h_meta;
       {
         uint8_t *recs = static_cast<uint8_t *>(ctx->records.p) + r.f0 * rec;
         const int crc = compact_launch(ctx, recs, r.nf, ch, d_blob + r.blob_off, ctx->down_stream);
         if (crc != GLC_OK) return prog.set_error(crc, "glc_encode: compaction launch failed");
       }
-      // header + raw flags + scale factors + list lengths: they say how long the payload is
-      e = hipMemcpyAsync(h_meta, d_blob + r.blob_off, r.l.o_pairs, hipMemcpyDeviceToHost, ctx->down_stream);
+      // One copy fetches the metadata (header, raw flags, scale factors, list lengths: they say how
+      // long the payload is) AND as much of the pair section behind it as this round is expected to
+      // fill, from the density of the stream so far (+ 25 %), into pinned memory; a round that holds
+      // more, or raw planes, fetches the rest straight into the pools once the header is known.
+      // (Queueing the last round's compaction and download behind its quantiser on the round's own
+      // stream, to save the launch latency, measured 70 us SLOWER at config 2.)
+      uint64_t guess_pairs = 0;
+      if (i > 0) guess_pairs = static_cast<uint64_t>(pairs_per_frame.load(std::memory_order_relaxed) * static_cast<double>(r.nf)) + 1024;
+      // ... for short rounds, where the second round trip is what costs; a long round's payload (3.7 MB
+      // for 4096 stereo frames) goes straight into the pools - the host copy out of the pinned buffer
+      // would cost more than the round trip (one hour of stereo: 61 ms with it, 54 without)
+      if (guess_pairs * 4 > (size_t(3) << 19)) guess_pairs = 0;
+      const uint64_t first_bytes = std::min<uint64_t>(r.l.o_pairs + guess_pairs * 4, std::min<uint64_t>(r.l.bound, stage_cap));
+      e = hipMemcpyAsync(hm, blob, first_bytes, hipMemcpyDeviceToHost, ctx->down_stream);
       if (e == hipSuccess) e = hipStreamSynchronize(ctx->down_stream);
       if (e != hipSuccess) return prog.set_error(GLC_EHIP, hip_msg("glc_encode: download", e));
       glc::CompactHeader h;
-      std::memcpy(&h, h_meta, sizeof h);
+      std::memcpy(&h, hm, sizeof h);
       if (h.magic != glc::kCompactMagic || h.n_frames != r.nf || h.channels != ch || h.bytes > r.l.bound ||
           h.n_pairs > r.nf * ch * glc::kHop || h.n_raw_rows > r.nf * ch)
         return prog.set_error(GLC_EHIP, "glc_encode: the device wrote an inconsistent compact header");
-      const uint8_t *blob = d_blob + r.blob_off;
       const uint64_t p_at = p_used, r_at = r_used;
       if (i == 0 && n_rounds > 1) {  // reserve the pools once from the first round's density (+ 30 %)
         const double scale = static_cast<double>(plan.n_frames) / static_cast<double>(r.nf) * 1.3;
@@ -731,16 +800,23 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
       if (F->raw.size() < r_at + h.n_raw_rows * glc::kFrame) F->raw.resize(r_at + h.n_raw_rows * glc::kFrame);
       p_used += h.n_pairs;
       r_used += h.n_raw_rows * glc::kFrame;
-      if (h.n_pairs) e = hipMemcpyAsync(F->pairs.data() + p_at, blob + r.l.o_pairs, h.n_pairs * 4, hipMemcpyDeviceToHost, ctx->down_stream);
+      pairs_per_frame.store(static_cast<double>(p_used) / static_cast<double>(r.f0 + r.nf) * 1.25, std::memory_order_relaxed);
+      const uint64_t have = std::min<uint64_t>(h.n_pairs, (first_bytes - r.l.o_pairs) / 4);  // pairs already on the host
+      if (h.n_pairs > have)
+        e = hipMemcpyAsync(F->pairs.data() + p_at + have, blob + r.l.o_pairs + have * 4, (h.n_pairs - have) * 4, hipMemcpyDeviceToHost,
+                           ctx->down_stream);
       if (e == hipSuccess && h.n_raw_rows)
         e = hipMemcpyAsync(F->raw.data() + r_at, blob + glc::compact_raw_offset(r.l, h.n_pairs), h.n_raw_rows * glc::kFrame * 2,
                            hipMemcpyDeviceToHost, ctx->down_stream);
+      if (have) std::memcpy(F->pairs.data() + p_at, hm + r.l.o_pairs, have * 4);
       bool canonical = true;
       int rc = GLC_OK;
-      if (e == hipSuccess) rc = glc::index_compact_meta(F.get(), ch, h, h_meta, r.f0, p_at, r_at, /*trusted=*/true, &canonical);
+      if (e == hipSuccess) rc = glc::index_compact_meta(F.get(), ch, h, hm, r.f0, p_at, r_at, /*trusted=*/true, &canonical);
       // the pools may move when the next round grows them, and h_meta is reused: all of it has to have landed
-      const hipError_t e2 = hipStreamSynchronize(ctx->down_stream);
-      if (e == hipSuccess) e = e2;
+      if (h.n_pairs > have || h.n_raw_rows) {
+        const hipError_t e2 = hipStreamSynchronize(ctx->down_stream);
+        if (e == hipSuccess) e = e2;
+      }
       if (e != hipSuccess) return prog.set_error(GLC_EHIP, hip_msg("glc_encode: download", e));
       if (rc != GLC_OK) return prog.set_error(rc, std::string("glc_encode: ") + glc_last_error(nullptr));
     }
@@ -754,13 +830,28 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
       launch();
       collect();
     } else {
-      std::thread t_up(upload);
-      std::thread t_launch;
+      if (!ctx->enc_up) ctx->enc_up.reset(new Worker);
+      if (!ctx->enc_launch) ctx->enc_launch.reset(new Worker);
+      auto guarded = [&prog](const std::function<void()> &f) {
+        return [&prog, f] {
+          try {
+            f();
+          } catch (...) {
+            try {
+              prog.set_error(GLC_ENOMEM, "glc_encode: host allocation failed");
+            } catch (...) {
+            }
+          }
+        };
+      };
+      bool up_started = false;
       try {
-        t_launch = std::thread(launch);
-      } catch (...) {
-        prog.set_error(GLC_ENOMEM, "glc_encode: cannot start a thread");
-        t_up.join();
+        ctx->enc_up->submit(guarded(upload));
+        up_started = true;
+        ctx->enc_launch->submit(guarded(launch));
+      } catch (...) {  // a helper could not be started: stop the other, report
+        prog.set_error(GLC_ENOMEM, "glc_encode: cannot start a helper thread");
+        if (up_started) ctx->enc_up->wait();
         throw;
       }
       try {
@@ -768,16 +859,16 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
       } catch (...) {
         prog.set_error(GLC_ENOMEM, "glc_encode: host allocation failed");
       }
-      t_up.join();
-      t_launch.join();
+      ctx->enc_up->wait();
+      ctx->enc_launch->wait();
     }
     std::lock_guard<std::mutex> lk(prog.mu);
     rc = prog.rc;
     msg = prog.msg;
   } catch (const std::bad_alloc &) {
     rc = GLC_ENOMEM, msg = "glc_encode: host allocation failed";
-  } catch (const std::system_error &) {
-    rc = GLC_ENOMEM, msg = "glc_encode: cannot start a thread";
+  } catch (...) {  // std::system_error from starting a helper thread; nothing may cross the C ABI
+    rc = GLC_ENOMEM, msg = "glc_encode: cannot start a helper thread";
   }
   if (rc != GLC_OK) {
     // nothing may still be in flight into the caller's or the result's memory when this returns
