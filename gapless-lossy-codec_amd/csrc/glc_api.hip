@@ -131,7 +131,8 @@ struct glc_ctx {
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;  // glc_ctx_timer_*
   hipStream_t copy_stream = nullptr;  // glc_encode: uploads run ahead of the kernels on this one
   hipEvent_t ev_copy = nullptr;
-  hipStream_t stream_b = nullptr;     // glc_encode: odd rounds are transformed here, beside the even ones on `stream`
+  hipStream_t stream_b = nullptr;     // odd rounds / chunks of an encode are transformed here, beside the even ones on `stream`
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // glc_encode_range_device: second stream after the caller's work, caller's stream after both
   DevBuf coef_b;                      // ... with a coefficient workspace of their own
   hipStream_t down_stream = nullptr;  // glc_encode: round i is compacted and its blob comes down while round i+1 is transformed
   std::vector<hipEvent_t> ev_round;   // one per round: records written
@@ -316,6 +317,8 @@ void glc_ctx_destroy(glc_ctx *ctx) {
   if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
   if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
   if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   for (hipEvent_t e : ctx->ev_dec)
     if (e) (void)hipEventDestroy(e);
   ctx->stream_out.release();
@@ -394,7 +397,7 @@ int glc_ctx_tables(const glc_ctx *ctx, float *cos_table, float *window, float *n
 // alternate rounds on two streams)
 static int encode_range_on(glc_ctx *ctx, hipStream_t stream, DevBuf &coef_ws, const float *d_pcm, uint64_t t0, uint64_t t_count,
                            uint64_t n_samples, uint16_t channels, uint64_t frame_begin, uint64_t frame_end,
-                           void *d_records, float *d_coeffs) {
+                           void *d_records, float *d_coeffs, bool alternate_ok = false) {
   if (!ctx || !d_pcm || !d_records) return fail(ctx, GLC_EINVAL, "glc_encode_range_device: null argument");
   const glc_plan plan = glc::plan_encode(n_samples, channels);
   if (plan.n_frames == 0)
@@ -423,15 +426,36 @@ static int encode_range_on(glc_ctx *ctx, hipStream_t stream, DevBuf &coef_ws, co
     const uint64_t rows = std::min<uint64_t>(chunk, frame_end - frame_begin) * ch;
     GLC_HIP(ctx, coef_ws.reserve(std::max<size_t>(rows, 1) * glc::kHop * sizeof(float)));
   }
-  for (uint64_t f = frame_begin; f < frame_end; f += chunk) {
+  // A range of several chunks alternates between the caller's stream and a second one (its own
+  // coefficient workspace): chunk c's quantiser then runs beside chunk c+1's transform instead of in
+  // front of it (six 4096-frame chunks: 3.78 -> 3.68 ms).  Fork and join by events, so the caller sees
+  // plain stream order: everything queued before the call is finished before the second stream
+  // starts, and the caller's stream continues only when both are done.
+  const bool alternate = alternate_ok && !d_coeffs && frame_end - frame_begin > chunk;
+  if (alternate) {
+    if (!ctx->stream_b) GLC_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_b, hipStreamNonBlocking));
+    if (!ctx->ev_fork) GLC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    if (!ctx->ev_join) GLC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    GLC_HIP(ctx, ctx->coef_b.reserve(static_cast<size_t>(chunk) * ch * glc::kHop * sizeof(float)));
+    GLC_HIP(ctx, hipEventRecord(ctx->ev_fork, stream));
+    GLC_HIP(ctx, hipStreamWaitEvent(ctx->stream_b, ctx->ev_fork, 0));
+  }
+  uint64_t c_idx = 0;
+  for (uint64_t f = frame_begin; f < frame_end; f += chunk, ++c_idx) {
     const uint64_t nf = std::min<uint64_t>(chunk, frame_end - f);
     const uint32_t M = static_cast<uint32_t>(nf * ch);
-    float *coef = d_coeffs ? d_coeffs + (f - frame_begin) * ch * glc::kHop : static_cast<float *>(coef_ws.p);
+    const bool odd = alternate && (c_idx & 1);
+    hipStream_t st = odd ? ctx->stream_b : stream;
+    float *coef = d_coeffs ? d_coeffs + (f - frame_begin) * ch * glc::kHop : static_cast<float *>(odd ? ctx->coef_b.p : coef_ws.p);
     uint8_t *r = recs + (f - frame_begin) * rec;
-    GLC_HIP(ctx, glc::launch_mdct_forward(ctx->dev, view, f, M, coef, stream));
+    GLC_HIP(ctx, glc::launch_mdct_forward(ctx->dev, view, f, M, coef, st));
     bool decided = false;
-    GLC_HIP(ctx, glc::launch_quantize(ctx->dev, coef, M, ch, view, f, r, stream, &decided));
-    if (!decided) GLC_HIP(ctx, glc::launch_decide_raw(ctx->dev, view, f, static_cast<uint32_t>(nf), r, stream));
+    GLC_HIP(ctx, glc::launch_quantize(ctx->dev, coef, M, ch, view, f, r, st, &decided));
+    if (!decided) GLC_HIP(ctx, glc::launch_decide_raw(ctx->dev, view, f, static_cast<uint32_t>(nf), r, st));
+  }
+  if (alternate) {
+    GLC_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream_b));
+    GLC_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_join, 0));
   }
   return GLC_OK;
 }
@@ -441,7 +465,7 @@ int glc_encode_range_device(glc_ctx *ctx, const float *d_pcm, uint64_t t0, uint6
                             uint64_t frame_end, void *d_records, float *d_coeffs) {
   if (!ctx) return GLC_EINVAL;
   return encode_range_on(ctx, ctx->stream, ctx->coef, d_pcm, t0, t_count, n_samples, channels, frame_begin, frame_end,
-                         d_records, d_coeffs);
+                         d_records, d_coeffs, /*alternate_ok=*/true);
 }
 
 int glc_mdct_forward_device(glc_ctx *ctx, const float *d_pcm, uint64_t t0, uint64_t t_count,
