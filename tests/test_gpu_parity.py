@@ -1049,3 +1049,37 @@ def test_host_encode_pipeline_across_density_changes(torch_cuda, ch, shape):
     info = got.info()
     if "raw" in shape:
         assert 0 < info.n_raw_frames < nf
+
+
+def test_multi_chunk_range_keeps_the_callers_stream_order(torch_cuda):
+    """glc_encode_range_device over several 4096-frame chunks forks onto a second stream and joins again:
+    on the CALLER's stream it must still behave like one in-order operation.  The samples are produced
+    by work queued on that stream right before the call (a device-to-device copy behind a long
+    fill), the records are consumed by work queued right after it (a copy into another buffer), with no
+    host synchronisation in between; the result equals the synchronised single-stream path."""
+    torch = torch_cuda
+    sr, ch, nf = 48000, 2, 3 * 4096 + 100
+    rng = np.random.default_rng(99)
+    t = np.arange(nf * 1024, dtype=np.float64)[:, None]
+    x = (np.sin(2 * np.pi * rng.uniform(100, 9000, (1, ch)) * t / sr) * 0.4).astype(np.float32)
+    x[5000 * 1024:5040 * 1024] = rng.standard_normal((40 * 1024, ch)).astype(np.float32) * 0.3  # raw frames in chunk 1
+    x = x.reshape(-1)
+    want, _ = device_encode(torch, x, sr, ch, want_coeffs=False)
+    rec = glc_amd.lib.glc_record_bytes(ch)
+    s = torch.cuda.Stream()
+    enc = glc_amd.Encoder(sr)
+    enc.set_stream(s.cuda_stream)
+    src = torch.from_numpy(x).cuda()
+    d_pcm = torch.zeros_like(src)
+    d_rec = torch.zeros(nf * rec, dtype=torch.uint8, device="cuda")
+    out = torch.zeros_like(d_rec)
+    junk = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        junk.fill_(1)                      # keeps the stream busy, so the copy below is still pending ...
+        d_pcm.copy_(src, non_blocking=True)
+        enc.encode_range_device(d_pcm.data_ptr(), 0, x.size // ch, x.size, ch, 0, nf, d_rec.data_ptr())  # ... when this is queued
+        out.copy_(d_rec, non_blocking=True)  # and this must see all three chunks' records
+    s.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+    enc.set_stream(0)
