@@ -1,7 +1,7 @@
 // decode_breakdown.cpp — the inverse transform (D1) and the whole device decode timed through the
 // C ABI without Python in the process, on BASELINE config 2 (4096 frames x 1024, stereo chord); the
 // like-for-like partner of tools/bench_d1.py and of the `L` family of tools/d1_tune.hip.
-// Build: make -C gapless-lossy-codec_amd/csrc tools      Usage: build/decode_breakdown [variants, e.g. 0,4,0,4] [reps = 100]
+// Build: make -C gapless-lossy-codec_amd/csrc tools      Usage: build/decode_breakdown [variants, e.g. 0,4,0,4] [reps = 100] [frames = 4096]
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -35,7 +35,7 @@
 int main(int argc, char **argv) {
   const char *variants = argc > 1 ? argv[1] : "0,4,0,4";
   const int reps = argc > 2 ? std::atoi(argv[2]) : 100;
-  const uint64_t frames = 4096;
+  const uint64_t frames = argc > 3 ? std::strtoull(argv[3], nullptr, 10) : 4096;
   const uint16_t ch = 2;
   const uint64_t per_ch = frames * 1024, n = per_ch * ch;
   std::vector<float> pcm(n);
@@ -71,7 +71,7 @@ int main(int argc, char **argv) {
     GL(glc_ctx_timer_begin(dec));
     for (int i = 0; i < reps; ++i) GL(glc_imdct_device(dec, F, 0, frames, d_blk));
     GL(glc_ctx_timer_end(dec, &ms));
-    std::printf("D1 debug variant %d: %7.1f us per launch (4096 stereo frames)\n", v, ms / reps * 1e3);
+    std::printf("D1 debug variant %d: %7.1f us per launch (%llu stereo frames)\n", v, ms / reps * 1e3, static_cast<unsigned long long>(frames));
     while (*p && *p != ',') ++p;
     if (*p == ',') ++p;
   }
