@@ -150,6 +150,14 @@ int main(int argc, char **argv) {
       Variant{"SHIPPED hipcc-scheduled 32x64 t4x4 (<= 512 rows)", k1::launch<32, 64, 32, 4, 4, 4, 2>},
       // tuning variants (tools/k1_variants.hpp)
       Variant{"dma segment loader, round-1 protocol: end-of-stage hand-off, counted vmcnt(1)", k1x::launch_dma<4, 0, 128, 2, 0>},
+      Variant{"dma segment loader, issue priority alternates between a CU's two workgroups every stage", k1x::launch_dma<4, 0, 128, 2, -1>},
+      Variant{"dma segment loader, ... every 2 stages", k1x::launch_dma<4, 0, 128, 2, -2>},
+      Variant{"dma segment loader, ... every 8 stages", k1x::launch_dma<4, 0, 128, 2, -8>},
+      Variant{"dma segment loader, no stagger (again)", k1x::launch_dma<4, 0, 128, 2, 0>},
+      Variant{"SHIPPED dma, segment loader (again: mid-stage hand-off)", k1::launch_dma<4, 2>},
+      Variant{"dma segment loader, end-of-stage hand-off (k1x, again)", k1x::launch_dma<4, 0, 128, 2, 0>},
+      Variant{"SHIPPED dma, segment loader (third time)", k1::launch_dma<4, 2>},
+      Variant{"dma segment loader, end-of-stage hand-off (k1x, third time)", k1x::launch_dma<4, 0, 128, 2, 0>},
       Variant{"dma segment loader, odd workgroups start 16 x 64 cycles late", k1x::launch_dma<4, 0, 128, 2, 16>},
       Variant{"dma segment loader, odd workgroups start 32 x 64 cycles late", k1x::launch_dma<4, 0, 128, 2, 32>},
       Variant{"dma segment loader, odd workgroups start 64 x 64 cycles late", k1x::launch_dma<4, 0, 128, 2, 64>},

@@ -827,6 +827,12 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
 #pragma unroll 1
   for (int s = 0; s < kStages; ++s) {
     const int slot = s % 3;
+    // STAGGER < 0 (tuning): issue priority alternates between the two workgroups of a CU (blocks b and
+    // b + 256) every -STAGGER stages, so that one of them runs ahead while the other fills its gaps
+    if constexpr (STAGGER < 0) {
+      if ((((s / (-STAGGER)) ^ static_cast<int>(blockIdx.x >> 8)) & 1) != 0) __builtin_amdgcn_s_setprio(2);
+      else __builtin_amdgcn_s_setprio(0);
+    }
     // in flight on entry: PCM loads of stage s+1 (regs) and table DMA of stage s+1 (slot (s+1)%3)
     if (ABL == 0) issue_b(((s + 2) & (kStages - 1)) * BK, (s + 2) % 3);  // slot of stage s-1: free since the barrier
     const unsigned a_addr = a_lds0 + slot * (BK * BM * 4);
