@@ -1083,3 +1083,52 @@ def test_multi_chunk_range_keeps_the_callers_stream_order(torch_cuda):
     s.synchronize()
     assert np.array_equal(out.cpu().numpy(), want)
     enc.set_stream(0)
+
+
+def test_pipelined_encode_contexts_come_and_go_and_run_side_by_side(torch_cuda):
+    """Multi-round glc_encode keeps two helper threads parked in its context: contexts that are created,
+    used for a few pipelined calls and destroyed in a loop must neither leak them nor hang on the way out,
+    and three host threads, each with its own context and its own many-round stream (one of them on a
+    stream torch owns), must all produce the bytes of the unpipelined device path."""
+    import threading
+    sr = 48000
+    streams = []
+    for i, ch in enumerate((2, 5, 1)):
+        piece = (2048 + ch - 1) // ch
+        nf = 4 * piece + 4096 + 300 + 17 * i   # four opening rounds, one full round, a ragged one
+        rng = np.random.default_rng(500 + i)
+        t = np.arange(nf * 1024, dtype=np.float64)[:, None]
+        x = (np.sin(2 * np.pi * rng.uniform(80, 7000, (1, ch)) * t / sr) * 0.35).astype(np.float32)
+        x[(piece + 3) * 1024:(piece + 9) * 1024] = rng.standard_normal((6 * 1024, ch)).astype(np.float32) * 0.3
+        x = x.reshape(-1)
+        recs, _ = device_encode(torch_cuda, x, sr, ch, want_coeffs=False)
+        streams.append((x, ch, glc_amd.EncodedAudio.from_records(sr, x.size, ch, recs).to_bytes()))
+    for _ in range(6):  # contexts come and go
+        enc = glc_amd.Encoder(sr)
+        for x, ch, want in streams[:2]:
+            assert enc.encode(x, ch).to_bytes() == want
+        enc.close()
+    errors = []
+
+    def work(i):
+        try:
+            x, ch, want = streams[i]
+            enc = glc_amd.Encoder(sr)
+            s = None
+            if i == 0:
+                s = torch_cuda.cuda.Stream()
+                enc.set_stream(s.cuda_stream)
+            for _ in range(5):
+                assert enc.encode(x, ch).to_bytes() == want
+            if s is not None:
+                enc.set_stream(0)
+            enc.close()
+        except BaseException as e:  # noqa: BLE001 - reported to the main thread
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
