@@ -806,6 +806,7 @@ void k_apply_pair(const float *T, const float *win, float norm, const unsigned *
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     if (!(live & (1u << g))) continue;
+    if (prio_step == 9999u && (g & 1)) continue;  // ablation: half the block stores (what a fused overlap-add would write)
     float *out = blocks + static_cast<size_t>((fr0 + g) * ch + c) * kFrameI + col0;
     d1x4 o0, o1;
     o0.x = mul_rn(mul_rn(acc[g][0].x, norm), w0.x); o0.y = mul_rn(mul_rn(acc[g][0].y, norm), w0.y);
@@ -1184,6 +1185,9 @@ int main(int argc, char **argv) {
       hipLaunchKernelGGL((k_apply_pair<true, 4, 2, 2, true>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, (unsigned long long *)nullptr, d_order, step);
     });
   }
+  run("C2 apply_pair alone, balanced, ABLATION: half of the block stores", false, [&] {
+    hipLaunchKernelGGL((k_apply_pair<true, 4, 2, 1, true>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, (unsigned long long *)nullptr, d_order, 9999u);
+  });
   run("C2 apply_pair alone, shipped (again)", true, [&] {
     hipLaunchKernelGGL((k_apply_pair<true, 4, 2, 1, true>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, (unsigned long long *)nullptr);
   });
