@@ -41,7 +41,7 @@ hipError_t launch_quantize(const DeviceTables &t, const float *coef, uint32_t M,
 hipError_t launch_decide_raw(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin,
                              uint32_t n_frames, uint8_t *records, hipStream_t s);
 
-// P1-P4: compact blob (glc_common.h CompactLayout) of M = n_frames*ch rows of records, written to
+// P1-P3: compact blob (glc_common.h CompactLayout) of M = n_frames*ch rows of records, written to
 // `blob` on the device: header, per-frame raw flags, per-row scale and pair count, the ascending
 // (u16 idx | i16 q << 16) pairs of every compressed row back to back, then the 2048-sample planes of
 // raw-frame rows.  loc[M], blk[ceil(M/1024)], blk_raw[same], totals[2] are scratch.  The alignment

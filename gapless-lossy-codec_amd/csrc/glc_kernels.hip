@@ -738,14 +738,14 @@ __global__ __launch_bounds__(256) void k_overlap_add(const float *__restrict__ b
 }
 
 // ------------------------------------------------------------------------------------------
-// P1-P4: device-side compaction of frame records into the compact blob (glc_common.h
+// P1-P3: device-side compaction of frame records into the compact blob (glc_common.h
 // CompactLayout), so that the host boundary and the multi-GPU gather move (u16 idx, i16 q) pairs
 // instead of dense 1024-bin rows.
 //   P1  per row: pairs it contributes (nnz, 0 for rows of raw frames); exclusive scan inside
 //       blocks of 1024 rows; per-row scale and count, per-frame raw flag into the blob
-//   P2  exclusive scan of the block totals (one workgroup)
-//   P3  blob header (needs the totals), zeroes the alignment gap in front of the raw section
-//   P4  one wave per row: ballot + popcount prefix keeps ascending k (src/codec.rs:303-306);
+//   P2  one workgroup: exclusive scans of the block totals (pairs, raw rows), then the blob header
+//       they determine and the zeroed alignment gap in front of the raw section
+//   P3  one wave per row: ballot + popcount prefix keeps ascending k (src/codec.rs:303-306);
 //       planes of raw-frame rows go to the raw section, which starts behind the pairs
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pack_scan_rows(const unsigned char *__restrict__ records, unsigned M,
