@@ -35,6 +35,56 @@ class GlcCompactInfo(C.Structure):
     ]
 
 
+class GlcFramesView(C.Structure):
+    """glc_frames_view (include/glc.h): EncodedAudio as flat arrays."""
+    _fields_ = [
+        ("sample_rate", C.c_uint32),
+        ("channels", C.c_uint16),
+        ("reserved", C.c_uint16),
+        ("total_samples", C.c_uint64),
+        ("encoder_delay", C.c_uint32),
+        ("padding", C.c_uint32),
+        ("original_length", C.c_uint64),
+        ("n_frames", C.c_uint64),
+        ("n_lists", C.c_uint64),
+        ("n_pairs", C.c_uint64),
+        ("n_scales", C.c_uint64),
+        ("n_raw", C.c_uint64),
+        ("list_begin", C.c_void_p),
+        ("list_off", C.c_void_p),
+        ("pairs", C.c_void_p),
+        ("scale_begin", C.c_void_p),
+        ("scales", C.c_void_p),
+        ("raw_tag", C.c_void_p),
+        ("raw_begin", C.c_void_p),
+        ("raw", C.c_void_p),
+    ]
+
+
+class GlcFramesGather(C.Structure):
+    """glc_frames_gather (include/glc.h): EncodedAudio by pointer per vector."""
+    _fields_ = [
+        ("sample_rate", C.c_uint32),
+        ("channels", C.c_uint16),
+        ("reserved", C.c_uint16),
+        ("total_samples", C.c_uint64),
+        ("encoder_delay", C.c_uint32),
+        ("padding", C.c_uint32),
+        ("original_length", C.c_uint64),
+        ("n_frames", C.c_uint64),
+        ("lists_per_frame", C.c_void_p),
+        ("list_ptr", C.c_void_p),
+        ("list_len", C.c_void_p),
+        ("scales_per_frame", C.c_void_p),
+        ("scale_ptr", C.c_void_p),
+        ("raw_ptr", C.c_void_p),
+        ("raw_len", C.c_void_p),
+    ]
+
+
+FRAMES_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(GlcFramesView), C.c_uint64, C.c_uint64)
+
+
 class GlcPlan(C.Structure):
     _fields_ = [
         ("n_frames", C.c_uint64),
@@ -94,6 +144,13 @@ SIGNATURES = {
                                    C.POINTER(C.c_uint32)]),
     "glc_frame_scale": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_float)]),
     "glc_frame_raw": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "glc_frames_get_view": (C.c_int, [_vp, C.POINTER(GlcFramesView)]),
+    "glc_frames_from_parts": (C.c_int, [C.POINTER(GlcFramesView), C.c_uint64, C.POINTER(_vp)]),
+    "glc_frames_from_gather": (C.c_int, [C.POINTER(GlcFramesGather), C.c_uint64, C.POINTER(_vp)]),
+    "glc_frames_stream_id": (C.c_uint64, [_vp]),
+    "glc_ctx_resident_stream": (C.c_uint64, [_vp]),
+    "glc_decode_resident": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "glc_encode_hooked": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint16, FRAMES_HOOK, _vp, C.POINTER(_vp)]),
     "glc_ctx_tables": (C.c_int, [_vp, _vp, _vp, C.POINTER(C.c_float), _vp, _vp,
                                  C.POINTER(C.c_uint32)]),
     "glc_wav_load": (C.c_int, [C.c_char_p, C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),

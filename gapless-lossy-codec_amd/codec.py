@@ -21,7 +21,8 @@ from typing import Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from ._lib import GLC_EINVAL, GlcCompactInfo, GlcError, GlcInfo, GlcPlan, check, lib
+from ._lib import (FRAMES_HOOK, GLC_EINVAL, GlcCompactInfo, GlcError, GlcFramesGather, GlcFramesView, GlcInfo, GlcPlan,
+                   check, lib)
 
 FRAME_SIZE = 2048        # src/codec.rs:15
 HOP_SIZE = 1024          # src/codec.rs:16
@@ -147,6 +148,81 @@ class EncodedAudio:
         check(lib.glc_deserialize(arr.ctypes.data_as(C.c_void_p), arr.size, C.byref(out)))
         return EncodedAudio(out.value)
 
+    # ---- the structured bridge (include/glc.h glc_frames_view): EncodedAudio as flat arrays ----------
+    _PART_TYPES = (("list_begin", np.uint64), ("list_off", np.uint64), ("pairs", np.uint32), ("scale_begin", np.uint64),
+                   ("scales", np.float32), ("raw_tag", np.uint8), ("raw_begin", np.uint64), ("raw", np.int16))
+
+    @property
+    def stream_id(self) -> int:
+        return int(lib.glc_frames_stream_id(self._h))
+
+    def parts(self) -> dict:
+        """Copies of the flat pools behind this EncodedAudio (glc_frames_get_view): header fields plus
+        list_begin / list_off / pairs / scale_begin / scales / raw_tag / raw_begin / raw as numpy arrays."""
+        v = GlcFramesView()
+        check(lib.glc_frames_get_view(self._h, C.byref(v)))
+        return _view_to_dict(v)
+
+    @staticmethod
+    def from_parts(parts: dict, stream_id: int = 0) -> "EncodedAudio":
+        """glc_frames_from_parts: the inverse of parts(); offsets are validated by the library."""
+        keep = {k: np.ascontiguousarray(parts[k], t).reshape(-1) for k, t in EncodedAudio._PART_TYPES}
+        v = GlcFramesView()
+        for k in ("sample_rate", "channels", "total_samples", "encoder_delay", "padding", "original_length"):
+            setattr(v, k, int(parts[k]))
+        v.n_frames = int(parts.get("n_frames", keep["raw_tag"].size))
+        v.n_lists = int(parts.get("n_lists", max(keep["list_off"].size, 1) - 1))
+        v.n_pairs = int(parts.get("n_pairs", keep["pairs"].size))
+        v.n_scales = int(parts.get("n_scales", keep["scales"].size))
+        v.n_raw = int(parts.get("n_raw", keep["raw"].size))
+        for k, _ in EncodedAudio._PART_TYPES:
+            setattr(v, k, keep[k].ctypes.data if keep[k].size else None)
+        out = C.c_void_p()
+        check(lib.glc_frames_from_parts(C.byref(v), stream_id, C.byref(out)))
+        return EncodedAudio(out.value)
+
+    @staticmethod
+    def from_nested(header: AudioHeader, frames, gapless: GaplessInfo, stream_id: int = 0) -> "EncodedAudio":
+        """glc_frames_from_gather from the reference's nested shape: `frames` is a sequence of
+        (sparse_coeffs_per_channel: list of uint32 arrays of packed (idx | q << 16) pairs,
+         scale_factors: float32 array, raw_pcm: int16 array or None) - one pointer per vector crosses."""
+        lists_per, list_ptr, list_len, scales_per, scale_ptr, raw_ptr, raw_len, keep = [], [], [], [], [], [], [], []
+        for lists, scales, raw in frames:
+            lists_per.append(len(lists))
+            for l in lists:
+                a = np.ascontiguousarray(l, np.uint32).reshape(-1)
+                keep.append(a)
+                list_ptr.append(a.ctypes.data if a.size else 0)
+                list_len.append(a.size)
+            sc = np.ascontiguousarray(scales, np.float32).reshape(-1)
+            keep.append(sc)
+            scales_per.append(sc.size)
+            scale_ptr.append(sc.ctypes.data if sc.size else 0)
+            if raw is None:
+                raw_ptr.append(0)
+                raw_len.append(0)
+            else:
+                r = np.ascontiguousarray(raw, np.int16).reshape(-1)
+                n_r = r.size
+                if n_r == 0:
+                    r = np.zeros(1, np.int16)  # Some(vec![]): a non-null pointer with length 0
+                keep.append(r)
+                raw_ptr.append(r.ctypes.data)
+                raw_len.append(n_r)
+        arr = lambda x, t: np.ascontiguousarray(np.array(x, dtype=t))
+        a_lp, a_ll, a_sp = arr(lists_per, np.uint32), arr(list_len, np.uint32), arr(scales_per, np.uint32)
+        a_ptr, a_sptr, a_rptr, a_rl = arr(list_ptr, np.uint64), arr(scale_ptr, np.uint64), arr(raw_ptr, np.uint64), arr(raw_len, np.uint64)
+        g = GlcFramesGather()
+        g.sample_rate, g.channels, g.total_samples = header.sample_rate, header.channels, header.total_samples
+        g.encoder_delay, g.padding, g.original_length = gapless.encoder_delay, gapless.padding, gapless.original_length
+        g.n_frames = len(lists_per)
+        for k, a in (("lists_per_frame", a_lp), ("list_ptr", a_ptr), ("list_len", a_ll), ("scales_per_frame", a_sp),
+                     ("scale_ptr", a_sptr), ("raw_ptr", a_rptr), ("raw_len", a_rl)):
+            setattr(g, k, a.ctypes.data if a.size else None)
+        out = C.c_void_p()
+        check(lib.glc_frames_from_gather(C.byref(g), stream_id, C.byref(out)))
+        return EncodedAudio(out.value)
+
     @staticmethod
     def from_records(sample_rate: int, n_samples: int, channels: int, records: np.ndarray) -> "EncodedAudio":
         """Assemble from the device path's fixed-size frame records (all shards, frame order)."""
@@ -174,6 +250,25 @@ class EncodedAudio:
         out = C.c_void_p()
         check(lib.glc_frames_from_compact(sample_rate, n_samples, channels, ptrs, sizes, n, C.byref(out)))
         return EncodedAudio(out.value)
+
+
+def _view_to_dict(v: GlcFramesView) -> dict:
+    def take(ptr, n, t):
+        if not n:
+            return np.empty(0, t)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(t))), shape=(n,)).copy()
+    d = {k: int(getattr(v, k)) for k in ("sample_rate", "channels", "total_samples", "encoder_delay", "padding",
+                                         "original_length", "n_frames", "n_lists", "n_pairs", "n_scales", "n_raw")}
+    nf = d["n_frames"]
+    d["list_begin"] = take(v.list_begin, nf + 1, np.uint64)
+    d["list_off"] = take(v.list_off, d["n_lists"] + 1, np.uint64)
+    d["pairs"] = take(v.pairs, d["n_pairs"], np.uint32)
+    d["scale_begin"] = take(v.scale_begin, nf + 1, np.uint64)
+    d["scales"] = take(v.scales, d["n_scales"], np.float32)
+    d["raw_tag"] = take(v.raw_tag, nf, np.uint8)
+    d["raw_begin"] = take(v.raw_begin, nf + 1, np.uint64)
+    d["raw"] = take(v.raw, d["n_raw"], np.int16)
+    return d
 
 
 def compact_bound(channels: int, n_frames: int) -> int:
@@ -262,6 +357,27 @@ class Encoder(_Ctx):
               self._h)
         return EncodedAudio(out.value)
 
+    def encode_hooked(self, samples, channels: int, hook) -> EncodedAudio:
+        """glc_encode_hooked: `hook(parts, frame_begin, frame_end)` is called each time a range of frames
+        has arrived on the host (while the device works on later ones); `parts` is the dict of
+        EncodedAudio.parts() for frames [0, frame_end).  A truthy return aborts the encode."""
+        pcm = np.ascontiguousarray(samples, np.float32).reshape(-1)
+        failure = []
+
+        def tramp(_user, view, f0, f1):
+            try:
+                return 1 if hook(_view_to_dict(view.contents), int(f0), int(f1)) else 0
+            except BaseException as e:  # no exception may cross the C frames
+                failure.append(e)
+                return 1
+        cb = FRAMES_HOOK(tramp)
+        out = C.c_void_p()
+        rc = lib.glc_encode_hooked(self._h, pcm.ctypes.data_as(C.c_void_p), pcm.size, channels, cb, None, C.byref(out))
+        if failure:
+            raise failure[0]
+        check(rc, self._h)
+        return EncodedAudio(out.value)
+
     def encode_range_device(self, d_pcm: int, t0: int, t_count: int, n_samples: int, channels: int,
                             frame_begin: int, frame_end: int, d_records: int, d_coeffs: int = 0) -> None:
         """Device-resident frame range (body of the rayon loop, src/codec.rs:462-541).  Pointers
@@ -326,6 +442,16 @@ class Decoder(_Ctx):
         got = C.c_uint64()
         check(lib.glc_decode(self._h, encoded._h, out.ctypes.data_as(C.c_void_p), n, C.byref(got)),
               self._h)
+        return out[:got.value]
+
+    def resident_stream(self) -> int:
+        """Identity of the stream whose sparse rows this context holds on the device (0: none)."""
+        return int(lib.glc_ctx_resident_stream(self._h))
+
+    def decode_resident(self, stream_id: int, out: np.ndarray) -> np.ndarray:
+        """glc_decode_resident: Decoder::decode of the resident stream without an EncodedAudio."""
+        got = C.c_uint64()
+        check(lib.glc_decode_resident(self._h, stream_id, out.ctypes.data_as(C.c_void_p), out.size, C.byref(got)), self._h)
         return out[:got.value]
 
     def decode_device(self, encoded: EncodedAudio, d_all: int, cap_all: int):

@@ -145,8 +145,12 @@ struct glc_ctx {
   DevBuf records;    // staging for host-boundary encode
   DevBuf blocks;     // decode: windowed IMDCT blocks [(chunk+1)][ch][2048]
   DevBuf dec_meta;   // decode: pairs / offsets / scales / raw pool
-  DevBuf dec_plan;   // decode: union records of the (group, channel) units of one D1 launch
+  DevBuf dec_plan;   // decode: union records of the (group, channel) units of one D1 launch (+ the unit order)
   uint32_t dec_plan_groups = 0;
+  // the launch whose plan records dec_plan still holds: a repeated launch of the same rows of the same
+  // stream skips k_imdct_plan (valid only for launches of one batch, plan_M != 0)
+  uint64_t plan_uid = 0;
+  uint32_t plan_row_begin = 0, plan_M = 0;
   DevBuf pack_meta;  // compaction scratch: loc, blk, blk_raw, totals
   DevBuf pack_blob;  // compaction: the compact blob of glc_encode / glc_frames_from_device_records
   HostBuf host_stage;  // pinned: the blob on its way to the host
@@ -154,6 +158,10 @@ struct glc_ctx {
   // decode session (decode_prepare / round_launch): device-resident sparse rows + position
   glc::DecodeRows dec_rows{};
   uint64_t dec_uid = 0;  // glc_frames::uid whose rows dec_meta holds (0: none)
+  // header of that stream (what glc_decode needs besides the rows) and a fingerprint of its pools: a
+  // caller-supplied stream id that comes back with different counts is treated as a new stream
+  uint32_t dec_delay = 0;
+  uint64_t dec_orig_len = 0, dec_n_pairs = 0, dec_n_raw = 0;
   int d1_variant = 0;    // include/glc_debug.h: which inverse-transform kernel / path to launch
   uint32_t dec_ch = 0;
   uint64_t dec_frames = 0, dec_next = 0;
@@ -173,7 +181,16 @@ constexpr uint64_t kDecodeChunkFrames = 4096;
 
 constexpr uint32_t kPlanGroups = 2048;  // (group, channel) units per D1 batch: 135 MB of workspace
 
+// glc_encode's helper threads run stages that report through fail(): they must not write ctx->err
+// (one std::string, two writers) - each helper points this at a string of its own for the duration of
+// its job, and the calling thread stores the winning message into ctx->err once, at the end.
+thread_local std::string *t_err_sink = nullptr;
+
 int fail(glc_ctx *ctx, int code, const std::string &msg) {
+  if (t_err_sink) {
+    *t_err_sink = msg;
+    return code;
+  }
   if (ctx) ctx->err = msg;
   glc::set_global_error(msg);
   return code;
@@ -607,8 +624,14 @@ int glc_frames_from_device_records(glc_ctx *ctx, const void *d_records, uint64_t
 
 int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t channels,
                glc_frames **out) {
-  if (!ctx || !pcm || !out) return fail(ctx, GLC_EINVAL, "glc_encode: null argument");
-  *out = nullptr;
+  if (!out) return fail(ctx, GLC_EINVAL, "glc_encode: null argument");
+  return glc_encode_hooked(ctx, pcm, n_samples, channels, nullptr, nullptr, out);
+}
+
+int glc_encode_hooked(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t channels,
+                      glc_frames_hook hook, void *hook_user, glc_frames **out) {
+  if (!ctx || !pcm || (!out && !hook)) return fail(ctx, GLC_EINVAL, "glc_encode: null argument");
+  if (out) *out = nullptr;
   const glc_plan plan = glc::plan_encode(n_samples, channels);
   if (plan.n_frames == 0)
     return fail(ctx, GLC_EINVAL,
@@ -757,6 +780,12 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
     }
   };
   auto launch = [&] {  // stage 2
+    std::string my_err;  // failures of this stage land here, not in ctx->err (another thread's to write)
+    struct SinkGuard {
+      std::string *prev;
+      explicit SinkGuard(std::string *s) : prev(t_err_sink) { t_err_sink = s; }
+      ~SinkGuard() { t_err_sink = prev; }
+    } sink(&my_err);
     DeviceGuard g(ctx->device);
     for (size_t i = 0; i < n_rounds; ++i) {
       const Round &r = rounds[i];
@@ -766,7 +795,7 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
       uint8_t *recs = static_cast<uint8_t *>(ctx->records.p) + r.f0 * rec;
       int rc = encode_range_on(ctx, cs, (i & 1) ? ctx->coef_b : ctx->coef, d_pcm, 0, t_count, n_samples, channels, r.f0,
                                r.f0 + r.nf, recs, nullptr);
-      if (rc != GLC_OK) return prog.set_error(rc, ctx->err);
+      if (rc != GLC_OK) return prog.set_error(rc, my_err);
       e = hipEventRecord(ev_rec[i], cs);
       if (e != hipSuccess) return prog.set_error(GLC_EHIP, hip_msg("glc_encode: queueing a round", e));
       prog.advance(prog.queued);
@@ -843,6 +872,18 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
       }
       if (e != hipSuccess) return prog.set_error(GLC_EHIP, hip_msg("glc_encode: download", e));
       if (rc != GLC_OK) return prog.set_error(rc, std::string("glc_encode: ") + glc_last_error(nullptr));
+      if (hook) {
+        // frames [r.f0, r.f0 + r.nf) are complete on the host; the device is busy with the later rounds
+        F->list_off.push_back(p_used);  // the view's closing offset (the final one is pushed at the end)
+        glc_frames_view v;
+        (void)glc_frames_get_view(F.get(), &v);
+        v.n_frames = r.f0 + r.nf;
+        v.n_pairs = p_used;
+        v.n_raw = r_used;
+        const int hrc = hook(hook_user, &v, r.f0, r.f0 + r.nf);
+        F->list_off.pop_back();
+        if (hrc != 0) return prog.set_error(GLC_EINVAL, "glc_encode_hooked: the hook asked to stop");
+      }
     }
   };
 
@@ -910,7 +951,7 @@ int glc_encode(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t chan
     return fail(ctx, GLC_ENOMEM, "glc_encode: host allocation failed");
   }
   F->lists_canonical = true;  // ballot-packed in ascending k
-  *out = F.release();
+  if (out) *out = F.release();
   return GLC_OK;
 }
 
@@ -940,17 +981,29 @@ int decode_prepare_impl(glc_ctx *ctx, const glc_frames *in) {
   const uint64_t M = nf * ch;
   if (M > 0xFFFFFFFFull) return fail(ctx, GLC_EINVAL, "glc_decode: stream too long");
   if (ctx->d1_variant != 1) {
+    // D1's plan workspace: one launch of this stream's (8-frame group, channel) units, at most kPlanGroups
+    // per batch (66 KB per unit: a 12-frame clip needs 4 units, not the 135 MB of a full batch)
     DeviceGuard guard_plan(ctx->device);
-    ctx->dec_plan_groups = std::max<uint32_t>(kPlanGroups, ch);  // at least one frame group of all channels
-    GLC_HIP(ctx, ctx->dec_plan.reserve(glc::imdct_plan_bytes(ctx->dec_plan_groups)));
+    const uint64_t units = ((nf + 7) / 8) * ch;
+    const uint32_t want = static_cast<uint32_t>(std::max<uint64_t>(ch, std::min<uint64_t>(std::max<uint32_t>(kPlanGroups, ch), units)));
+    if (want > ctx->dec_plan_groups) {
+      GLC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // queued launches may still read the old workspace
+      GLC_HIP(ctx, ctx->dec_plan.reserve(glc::imdct_plan_bytes(want)));
+      ctx->dec_plan_groups = want;
+      ctx->plan_uid = 0;
+    }
   }
   // The sparse rows of this stream are still on the device from an earlier call (a glc_frames is
-  // immutable and its uid is unique in the process): nothing to prepare or upload.
-  if (ctx->dec_uid != 0 && ctx->dec_uid == in->uid) {
+  // immutable and its uid is unique in the process, or a caller-supplied identity of the content;
+  // the pool sizes are compared as well, so that a recycled id does not silently decode old rows).
+  if (ctx->dec_uid != 0 && ctx->dec_uid == in->uid && ctx->dec_frames == nf && ctx->dec_ch == ch &&
+      ctx->dec_n_pairs == in->pairs.size() && ctx->dec_n_raw == in->raw.size() && ctx->dec_delay == in->encoder_delay &&
+      ctx->dec_orig_len == in->original_length) {
     ctx->dec_next = 0;
     return GLC_OK;
   }
   ctx->dec_uid = 0;
+  ctx->plan_uid = 0;
 
   // The five per-row arrays are built in ONE host block in the layout they have on the device, so that
   // they go up in one copy (each copy from pageable memory costs ~20 us before it moves a byte: eight
@@ -1053,6 +1106,29 @@ int decode_prepare_impl(glc_ctx *ctx, const glc_frames *in) {
   ctx->dec_frames = nf;
   ctx->dec_next = 0;
   ctx->dec_uid = in->uid;
+  ctx->dec_delay = in->encoder_delay;
+  ctx->dec_orig_len = in->original_length;
+  ctx->dec_n_pairs = in->pairs.size();
+  ctx->dec_n_raw = in->raw.size();
+  return GLC_OK;
+}
+
+// D1 for rows [row_begin, row_begin + M) of the prepared stream.  A launch that fits one batch of the
+// plan workspace leaves its plan records (and the unit order) behind; the same launch of the same
+// stream again - a repeated decode - skips k_imdct_plan.
+int launch_d1(glc_ctx *ctx, uint32_t row_begin, uint32_t M, float *blocks) {
+  const uint32_t ch = ctx->dec_ch;
+  const bool planned = ctx->d1_variant != 1 && ch != 0 && M % ch == 0;
+  const bool one_batch = planned && ((M / ch + 7) / 8) * ch <= ctx->dec_plan_groups;
+  const bool reuse = one_batch && ctx->plan_uid == ctx->dec_uid && ctx->plan_uid != 0 && ctx->plan_row_begin == row_begin &&
+                     ctx->plan_M == M;
+  GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, row_begin, M, ch, blocks, ctx->stream, ctx->d1_variant,
+                                      ctx->dec_plan.p, ctx->dec_plan.p ? ctx->dec_plan_groups : 0, reuse));
+  if (planned) {
+    ctx->plan_uid = one_batch ? ctx->dec_uid : 0;
+    ctx->plan_row_begin = row_begin;
+    ctx->plan_M = M;
+  }
   return GLC_OK;
 }
 
@@ -1072,11 +1148,11 @@ int round_launch(glc_ctx *ctx, uint64_t round_frames, bool flush_at_full, float 
   const size_t slot = static_cast<size_t>(ch) * glc::kFrame;  // floats per frame
   DeviceGuard guard(ctx->device);
   float *blocks = static_cast<float *>(ctx->blocks.p);
-  if (f0 == 0) GLC_HIP(ctx, hipMemsetAsync(blocks, 0, slot * sizeof(float), ctx->stream));  // overlap = 0.0, :601
-  if (n)
-    GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, static_cast<uint32_t>(f0 * ch),
-                                        static_cast<uint32_t>(n * ch), ch, blocks + slot, ctx->stream,
-                                        ctx->d1_variant, ctx->dec_plan.p, ctx->dec_plan.p ? ctx->dec_plan_groups : 0));
+  // (overlap = 0.0 before the first frame, :601: the overlap-add never reads slot 0 for hop 0)
+  if (n) {
+    const int rc = launch_d1(ctx, static_cast<uint32_t>(f0 * ch), static_cast<uint32_t>(n * ch), blocks + slot);
+    if (rc != GLC_OK) return rc;
+  }
   GLC_HIP(ctx, glc::launch_overlap_add(blocks, static_cast<int64_t>(f0) - 1, nf, ch, f0, f0 + n + (last ? 1 : 0), dout,
                                        ctx->stream));
   if (!last)
@@ -1112,19 +1188,18 @@ int decode_hops_prepared(glc_ctx *ctx, uint64_t hop_begin, uint64_t hop_end, flo
   const size_t slot = static_cast<size_t>(ch) * glc::kFrame;
   GLC_HIP(ctx, ctx->blocks.reserve((chunk + 1) * slot * sizeof(float)));
   float *blocks = static_cast<float *>(ctx->blocks.p);
-  if (hop_begin == 0)
-    GLC_HIP(ctx, hipMemsetAsync(blocks, 0, slot * sizeof(float), ctx->stream));  // overlap = 0.0, :601
-  else
-    GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, static_cast<uint32_t>((hop_begin - 1) * ch), ch, ch,
-                                        blocks, ctx->stream, ctx->d1_variant, ctx->dec_plan.p, ctx->dec_plan.p ? ctx->dec_plan_groups : 0));
+  if (hop_begin != 0) {  // (hop 0 has no frame before it: overlap = 0.0, :601, and slot 0 is never read for it)
+    const int rc = launch_d1(ctx, static_cast<uint32_t>((hop_begin - 1) * ch), ch, blocks);
+    if (rc != GLC_OK) return rc;
+  }
   uint64_t f0 = hop_begin;
   do {
     const uint64_t nchunk = f0 < f_end ? std::min(chunk, f_end - f0) : 0;
     const bool tail = f0 + nchunk == nf && hop_end == nf + 1;  // this round also emits the bare overlap tail
-    if (nchunk)
-      GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, static_cast<uint32_t>(f0 * ch),
-                                          static_cast<uint32_t>(nchunk * ch), ch, blocks + slot, ctx->stream,
-                                          ctx->d1_variant, ctx->dec_plan.p, ctx->dec_plan.p ? ctx->dec_plan_groups : 0));
+    if (nchunk) {
+      const int rc = launch_d1(ctx, static_cast<uint32_t>(f0 * ch), static_cast<uint32_t>(nchunk * ch), blocks + slot);
+      if (rc != GLC_OK) return rc;
+    }
     GLC_HIP(ctx, glc::launch_overlap_add(blocks, static_cast<int64_t>(f0) - 1, nf, ch, f0, f0 + nchunk + (tail ? 1 : 0),
                                          d_out + (f0 - hop_begin) * glc::kHop * ch, ctx->stream));
     f0 += nchunk + (tail ? 1 : 0);
@@ -1137,33 +1212,33 @@ int decode_hops_prepared(glc_ctx *ctx, uint64_t hop_begin, uint64_t hop_end, flo
 
 }  // namespace
 
-int glc_decode(glc_ctx *ctx, const glc_frames *in, float *pcm_out, uint64_t cap, uint64_t *n_out) {
-  if (!ctx || !in || (!pcm_out && cap)) return fail(ctx, GLC_EINVAL, "glc_decode: null argument");
-  ctx->stream_open = false;
+// Decoder::decode of the prepared session into host memory (src/codec.rs:744-768).
+static int decode_prepared_to_host(glc_ctx *ctx, float *pcm_out, uint64_t cap, uint64_t *n_out, const char *who) {
+  const uint64_t n_frames = ctx->dec_frames;
+  const uint32_t channels = ctx->dec_ch;
   // gapless trim, src/codec.rs:756-765 (delay counted in INTERLEAVED samples, quirk Q3)
-  const uint64_t all = (in->n_frames + 1) * static_cast<uint64_t>(glc::kHop) * in->channels;
+  const uint64_t all = (n_frames + 1) * static_cast<uint64_t>(glc::kHop) * channels;
   uint64_t start = 0, n = all;
-  if (n > in->encoder_delay) {
-    start = in->encoder_delay;
-    n -= in->encoder_delay;
+  if (n > ctx->dec_delay) {
+    start = ctx->dec_delay;
+    n -= ctx->dec_delay;
   }
-  if (n > in->original_length) n = in->original_length;
+  if (n > ctx->dec_orig_len) n = ctx->dec_orig_len;
   if (n_out) *n_out = n;
-  if (cap < n) return fail(ctx, GLC_EINVAL, "glc_decode: output buffer too small");
-  int rc = decode_prepare(ctx, in);
-  if (rc != GLC_OK) return rc;
+  if (cap < n) return fail(ctx, GLC_EINVAL, std::string(who) + ": output buffer too small");
+  ctx->dec_next = 0;
   // Rounds of 4096 frames through two device output buffers: the kernels of round r+1 are queued
   // before round r is copied out (on the copy stream, behind that round's event), so the D2H of
   // one round overlaps the decode of the next.  The block ring is sized once: slot 0 carries state.
-  const uint64_t round = std::max<uint64_t>(1, std::min<uint64_t>(kDecodeChunkFrames, in->n_frames));
-  const uint64_t per_hop = static_cast<uint64_t>(glc::kHop) * in->channels;
+  const uint64_t round = std::max<uint64_t>(1, std::min<uint64_t>(kDecodeChunkFrames, n_frames));
+  const uint64_t per_hop = static_cast<uint64_t>(glc::kHop) * channels;
   const size_t bufcap = static_cast<size_t>(round + 1) * per_hop;  // floats per output buffer
   {
     DeviceGuard guard(ctx->device);
-    GLC_HIP(ctx, ctx->blocks.reserve((round + 1) * static_cast<size_t>(in->channels) * glc::kFrame * sizeof(float)));
+    GLC_HIP(ctx, ctx->blocks.reserve((round + 1) * static_cast<size_t>(channels) * glc::kFrame * sizeof(float)));
     GLC_HIP(ctx, ctx->pcm.reserve(2 * bufcap * sizeof(float)));
   }
-  rc = ensure_copy_objects(ctx);
+  int rc = ensure_copy_objects(ctx);
   if (rc != GLC_OK) return rc;
   DeviceGuard guard(ctx->device);
   float *stage = static_cast<float *>(ctx->pcm.p);
@@ -1193,6 +1268,26 @@ int glc_decode(glc_ctx *ctx, const glc_frames *in, float *pcm_out, uint64_t cap,
     buf ^= 1;
   }
   return GLC_OK;
+}
+
+int glc_decode(glc_ctx *ctx, const glc_frames *in, float *pcm_out, uint64_t cap, uint64_t *n_out) {
+  if (!ctx || !in || (!pcm_out && cap)) return fail(ctx, GLC_EINVAL, "glc_decode: null argument");
+  ctx->stream_open = false;
+  if (n_out) *n_out = glc_decoded_len(in);
+  if (cap < glc_decoded_len(in)) return fail(ctx, GLC_EINVAL, "glc_decode: output buffer too small");
+  const int rc = decode_prepare(ctx, in);
+  if (rc != GLC_OK) return rc;
+  return decode_prepared_to_host(ctx, pcm_out, cap, n_out, "glc_decode");
+}
+
+uint64_t glc_ctx_resident_stream(const glc_ctx *ctx) { return ctx ? ctx->dec_uid : 0; }
+
+int glc_decode_resident(glc_ctx *ctx, uint64_t stream_id, float *pcm_out, uint64_t cap, uint64_t *n_out) {
+  if (!ctx || (!pcm_out && cap)) return fail(ctx, GLC_EINVAL, "glc_decode_resident: null argument");
+  if (stream_id == 0 || ctx->dec_uid != stream_id)
+    return fail(ctx, GLC_EINVAL, "glc_decode_resident: that stream is not resident on this context");
+  ctx->stream_open = false;
+  return decode_prepared_to_host(ctx, pcm_out, cap, n_out, "glc_decode_resident");
 }
 
 int glc_decode_device(glc_ctx *ctx, const glc_frames *in, float *d_all, uint64_t cap_all, uint64_t *start,
@@ -1238,10 +1333,7 @@ int glc_imdct_device(glc_ctx *ctx, const glc_frames *in, uint64_t frame_begin, u
   if (rc != GLC_OK) return rc;
   DeviceGuard guard(ctx->device);
   const uint32_t ch = ctx->dec_ch;
-  GLC_HIP(ctx, glc::launch_imdct_rows(ctx->dev, ctx->dec_rows, static_cast<uint32_t>(frame_begin * ch),
-                                      static_cast<uint32_t>((frame_end - frame_begin) * ch), ch, d_blocks, ctx->stream,
-                                      ctx->d1_variant, ctx->dec_plan.p, ctx->dec_plan.p ? ctx->dec_plan_groups : 0));
-  return GLC_OK;
+  return launch_d1(ctx, static_cast<uint32_t>(frame_begin * ch), static_cast<uint32_t>((frame_end - frame_begin) * ch), d_blocks);
 }
 
 int glc_debug_set_imdct_variant(glc_ctx *ctx, int variant) {

@@ -62,7 +62,9 @@ namespace glc {
 
 uint64_t next_frames_uid() {
   static std::atomic<uint64_t> counter{0};
-  return counter.fetch_add(1, std::memory_order_relaxed) + 1;
+  // library-made identities live in the upper half of the id space; the lower half belongs to the
+  // caller-supplied stream ids of glc_frames_from_parts / _gather
+  return (counter.fetch_add(1, std::memory_order_relaxed) + 1) | (1ull << 63);
 }
 
 // Index vectors of EncodedAudio for the frames of ONE compact blob whose payload (pairs, raw planes)
@@ -610,6 +612,194 @@ int glc_frame_raw(const glc_frames *f, uint64_t frame, int16_t *pcm, uint64_t ca
   if (pcm) std::memcpy(pcm, f->raw.data() + a, sizeof(int16_t) * ((b - a) < cap ? (b - a) : cap));
   return GLC_OK;
 }
+
+// ---- the structured bridge: EncodedAudio as flat arrays (include/glc.h) ----------------------
+
+int glc_frames_get_view(const glc_frames *f, glc_frames_view *out) {
+  if (!f || !out) return GLC_EINVAL;
+  std::memset(out, 0, sizeof *out);
+  out->sample_rate = f->sample_rate;
+  out->channels = f->channels;
+  out->total_samples = f->total_samples;
+  out->encoder_delay = f->encoder_delay;
+  out->padding = f->padding;
+  out->original_length = f->original_length;
+  out->n_frames = f->n_frames;
+  out->n_lists = f->list_off.empty() ? 0 : f->list_off.size() - 1;
+  out->n_pairs = f->pairs.size();
+  out->n_scales = f->scales.size();
+  out->n_raw = f->raw.size();
+  out->list_begin = f->list_begin.data();
+  out->list_off = f->list_off.data();
+  out->pairs = f->pairs.data();
+  out->scale_begin = f->scale_begin.data();
+  out->scales = f->scales.data();
+  out->raw_tag = f->raw_tag.data();
+  out->raw_begin = f->raw_begin.data();
+  out->raw = f->raw.data();
+  return GLC_OK;
+}
+
+namespace {
+
+// offsets[0 .. n] must start at 0, never decrease and end at `total`
+bool offsets_ok(const uint64_t *off, uint64_t n, uint64_t total) {
+  if (!off || off[0] != 0 || off[n] != total) return false;
+  for (uint64_t i = 0; i < n; ++i)
+    if (off[i] > off[i + 1]) return false;
+  return true;
+}
+
+int assign_uid(glc_frames *F, uint64_t stream_id) {
+  if (stream_id >> 63) {
+    glc::set_global_error("stream_id must be below 2^63 (the upper half identifies library-made objects)");
+    return GLC_EINVAL;
+  }
+  if (stream_id) F->uid = stream_id;
+  return GLC_OK;
+}
+
+}  // namespace
+
+int glc_frames_from_parts(const glc_frames_view *p, uint64_t stream_id, glc_frames **out) {
+  if (!p || !out) return GLC_EINVAL;
+  *out = nullptr;
+  const uint64_t nf = p->n_frames;
+  // every count must be addressable before anything is read through it
+  if (nf > (1ull << 40) || p->n_lists > (1ull << 44) || p->n_pairs > (1ull << 46) || p->n_scales > (1ull << 44) ||
+      p->n_raw > (1ull << 46)) {
+    glc::set_global_error("glc_frames_from_parts: absurd counts");
+    return GLC_EFORMAT;
+  }
+  if (!p->list_begin || !p->list_off || !p->scale_begin || !p->raw_begin || (nf && !p->raw_tag) ||
+      (p->n_pairs && !p->pairs) || (p->n_scales && !p->scales) || (p->n_raw && !p->raw)) {
+    glc::set_global_error("glc_frames_from_parts: null array");
+    return GLC_EINVAL;
+  }
+  if (!offsets_ok(p->list_begin, nf, p->n_lists) || !offsets_ok(p->list_off, p->n_lists, p->n_pairs) ||
+      !offsets_ok(p->scale_begin, nf, p->n_scales) || !offsets_ok(p->raw_begin, nf, p->n_raw)) {
+    glc::set_global_error("glc_frames_from_parts: offsets are not monotonic or do not span their pool");
+    return GLC_EFORMAT;
+  }
+  for (uint64_t f = 0; f < nf; ++f)
+    if (p->raw_tag[f] > 1 || (!p->raw_tag[f] && p->raw_begin[f + 1] != p->raw_begin[f])) {
+      glc::set_global_error("glc_frames_from_parts: raw_tag is not 0 / 1, or a frame without raw_pcm owns raw samples");
+      return GLC_EFORMAT;
+    }
+  std::unique_ptr<glc_frames> F(new (std::nothrow) glc_frames);
+  if (!F) return GLC_ENOMEM;
+  const int rc = assign_uid(F.get(), stream_id);
+  if (rc != GLC_OK) return rc;
+  try {
+    F->sample_rate = p->sample_rate;
+    F->channels = p->channels;
+    F->total_samples = p->total_samples;
+    F->encoder_delay = p->encoder_delay;
+    F->padding = p->padding;
+    F->original_length = p->original_length;
+    F->n_frames = nf;
+    F->list_begin.assign(p->list_begin, p->list_begin + nf + 1);
+    F->list_off.assign(p->list_off, p->list_off + p->n_lists + 1);
+    F->pairs.assign(p->pairs, p->pairs + p->n_pairs);
+    F->scale_begin.assign(p->scale_begin, p->scale_begin + nf + 1);
+    F->scales.assign(p->scales, p->scales + p->n_scales);
+    F->raw_tag.assign(p->raw_tag, p->raw_tag + nf);
+    F->raw_begin.assign(p->raw_begin, p->raw_begin + nf + 1);
+    F->raw.assign(p->raw, p->raw + p->n_raw);
+  } catch (const std::bad_alloc &) {
+    return GLC_ENOMEM;
+  }
+  F->lists_canonical = false;  // checked at decode
+  *out = F.release();
+  return GLC_OK;
+}
+
+int glc_frames_from_gather(const glc_frames_gather *g, uint64_t stream_id, glc_frames **out) {
+  if (!g || !out) return GLC_EINVAL;
+  *out = nullptr;
+  const uint64_t nf = g->n_frames;
+  if (nf > (1ull << 40)) {
+    glc::set_global_error("glc_frames_from_gather: absurd frame count");
+    return GLC_EFORMAT;
+  }
+  if (nf && (!g->lists_per_frame || !g->scales_per_frame || !g->scale_ptr || !g->raw_ptr || !g->raw_len)) {
+    glc::set_global_error("glc_frames_from_gather: null array");
+    return GLC_EINVAL;
+  }
+  std::unique_ptr<glc_frames> F(new (std::nothrow) glc_frames);
+  if (!F) return GLC_ENOMEM;
+  const int rc = assign_uid(F.get(), stream_id);
+  if (rc != GLC_OK) return rc;
+  try {
+    F->sample_rate = g->sample_rate;
+    F->channels = g->channels;
+    F->total_samples = g->total_samples;
+    F->encoder_delay = g->encoder_delay;
+    F->padding = g->padding;
+    F->original_length = g->original_length;
+    F->n_frames = nf;
+    F->list_begin.assign(nf + 1, 0);
+    F->scale_begin.assign(nf + 1, 0);
+    F->raw_begin.assign(nf + 1, 0);
+    F->raw_tag.assign(nf, 0);
+    // pass 1: sizes
+    uint64_t n_lists = 0, n_pairs = 0, n_scales = 0, n_raw = 0;
+    for (uint64_t f = 0; f < nf; ++f) {
+      const uint32_t nl = g->lists_per_frame[f];
+      if (nl && (!g->list_ptr || !g->list_len)) {
+        glc::set_global_error("glc_frames_from_gather: null list array");
+        return GLC_EINVAL;
+      }
+      for (uint32_t l = 0; l < nl; ++l) {
+        if (g->list_len[n_lists + l] && !g->list_ptr[n_lists + l]) {
+          glc::set_global_error("glc_frames_from_gather: null list pointer with a non-zero length");
+          return GLC_EINVAL;
+        }
+        n_pairs += g->list_len[n_lists + l];
+      }
+      n_lists += nl;
+      if (g->scales_per_frame[f] && !g->scale_ptr[f]) {
+        glc::set_global_error("glc_frames_from_gather: null scale pointer with a non-zero length");
+        return GLC_EINVAL;
+      }
+      n_scales += g->scales_per_frame[f];
+      if (g->raw_ptr[f]) {
+        F->raw_tag[f] = 1;
+        n_raw += g->raw_len[f];
+      }
+      F->list_begin[f + 1] = n_lists;
+      F->scale_begin[f + 1] = n_scales;
+      F->raw_begin[f + 1] = n_raw;
+    }
+    F->list_off.resize(n_lists + 1);
+    F->pairs.resize(n_pairs);
+    F->scales.resize(n_scales);
+    F->raw.resize(n_raw);
+    // pass 2: payload, one copy per vector
+    uint64_t li = 0, pi = 0;
+    for (uint64_t f = 0; f < nf; ++f) {
+      const uint32_t nl = g->lists_per_frame[f];
+      for (uint32_t l = 0; l < nl; ++l, ++li) {
+        F->list_off[li] = pi;
+        const uint32_t n = g->list_len[li];
+        if (n) std::memcpy(F->pairs.data() + pi, g->list_ptr[li], static_cast<size_t>(n) * 4);
+        pi += n;
+      }
+      const uint32_t ns = g->scales_per_frame[f];
+      if (ns) std::memcpy(F->scales.data() + F->scale_begin[f], g->scale_ptr[f], static_cast<size_t>(ns) * 4);
+      if (g->raw_ptr[f] && g->raw_len[f])
+        std::memcpy(F->raw.data() + F->raw_begin[f], g->raw_ptr[f], g->raw_len[f] * 2);
+    }
+    F->list_off[n_lists] = pi;
+  } catch (const std::bad_alloc &) {
+    return GLC_ENOMEM;
+  }
+  F->lists_canonical = false;  // checked at decode
+  *out = F.release();
+  return GLC_OK;
+}
+
+uint64_t glc_frames_stream_id(const glc_frames *f) { return f ? f->uid : 0; }
 
 uint64_t glc_decoded_len(const glc_frames *f) {
   if (!f) return 0;

@@ -67,10 +67,12 @@ struct DecodeRows {
 // by scalar branches); 1 = one row per workgroup (the cross-check kernel); 2 = plan + apply without
 // the skip; 3 = without the issue-priority schedule; 4 = skipping in row pairs only.  All but 1 need a workspace `plan` of imdct_plan_bytes(plan_groups) bytes,
 // plan_groups >= ch (launches with more (frame group, channel) units go through it in batches).
+// reuse_plan: the workspace still holds the plan records of exactly this launch (same rows, same
+// row_begin and M, one batch) - only the apply kernel runs.
 uint64_t imdct_plan_bytes(uint32_t groups);
 hipError_t launch_imdct_rows(const DeviceTables &t, const DecodeRows &rows, uint32_t row_begin,
                              uint32_t M, uint32_t ch, float *blocks, hipStream_t s, int variant = 0,
-                             void *plan = nullptr, uint32_t plan_groups = 0);
+                             void *plan = nullptr, uint32_t plan_groups = 0, bool reuse_plan = false);
 // D2: overlap-add + interleave of hops [hop_begin, hop_end) into out (hop h = second half of
 // frame h-1 + first half of frame h; hop n_frames is the bare overlap tail).  `blocks` holds
 // frames blk_frame0, blk_frame0+1, ... (blk_frame0 may be -1: a zero "frame before the first").

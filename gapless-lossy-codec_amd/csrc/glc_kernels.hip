@@ -338,11 +338,14 @@ __global__ __launch_bounds__(256) void k_imdct_rows(DeviceTables tb, DecodeRows 
 // k; a row that lacks an index of the union multiplies the table row by its +0.0 and adds the signed
 // zero, which is the identity on a running sum that is never -0.0 (the same identity the sparse skip
 // of the one-row kernel rests on).
-//   k_imdct_plan   one workgroup per (group, channel): raw rows are written out directly; the other
-//                  rows are dequantised into LDS, the ascending union of their indices is built and
-//                  written to global memory as 64-byte records {8 coefficients (+0.0 = absent), byte
-//                  offset of the table row of entry j+2}, with a header {n_u, live rows, offsets of
-//                  entries 0 and 1}.
+//   k_imdct_plan   one workgroup per (group, channel): the rows are dequantised into LDS, the ascending
+//                  union of their indices is built and written to global memory as 64-byte records
+//                  {8 coefficients (+0.0 = absent), byte offset of the table row of entry j+2}, with a
+//                  header {n_u, live rows, offsets of entries 0 and 1, dense flag, rows of raw frames}
+//                  and the unit's work for k_imdct_order.  Nothing here depends on where the blocks
+//                  go: the records of a launch stay valid for as long as the context holds the
+//                  stream's rows, and a repeated decode skips this kernel (glc_api.hip launch_d1).
+//   k_imdct_order  ranks the units of a launch by work and deals them over the CUs (speed only).
 //   k_imdct_apply  no LDS, no barrier: each wave owns 8 rows x 512 outputs.  The record of the next
 //                  entry arrives by scalar loads (s_load_dwordx8 + s_load_dword) a whole entry ahead;
 //                  the coefficient pairs feed v_pk_mul_f32 straight from SGPRs (lane-broadcast by
@@ -362,7 +365,7 @@ constexpr unsigned kPlanRecCap = kHopI + 8;   // per group: the union holds <= 1
 
 __global__ __launch_bounds__(256) void k_imdct_plan(DecodeRows rows, unsigned row_begin, unsigned n_frames, unsigned ch,
                                                      unsigned group_begin, unsigned ahead, unsigned *__restrict__ plan_hdr,
-                                                     unsigned *__restrict__ plan_rec, float *__restrict__ blocks) {
+                                                     unsigned *__restrict__ plan_rec, unsigned *__restrict__ plan_work) {
   constexpr int G = 8;
   __shared__ __attribute__((aligned(16))) float s_c[kHopI * G];
   __shared__ unsigned s_mask[kHopI / 32];
@@ -377,13 +380,12 @@ __global__ __launch_bounds__(256) void k_imdct_plan(DecodeRows rows, unsigned ro
   // of the 8 rows by 8 lanes at once (broadcast by shuffles afterwards) while the LDS is zeroed, then
   // the first 256 pairs of ALL rows before any of them is scattered.
   long long raw_l = -1;
-  unsigned long long p0_l = 0, rawlen_l = 0;
+  unsigned long long p0_l = 0;
   unsigned n_l = 0, valid_l = 0;
   float scale_l = 0.0f;
   if (lane < G && fr0 + lane < n_frames) {
     const unsigned m = row_begin + (fr0 + lane) * ch + c;
     raw_l = rows.row_raw[m];
-    rawlen_l = rows.row_raw_len[m];
     p0_l = rows.row_begin[m];
     n_l = min(rows.row_cnt[m], static_cast<unsigned>(kHopI));  // canonical lists hold <= 1024
     scale_l = fmaxf(rows.row_scale[m], 1e-12f);                  // :653
@@ -430,22 +432,6 @@ __global__ __launch_bounds__(256) void k_imdct_plan(DecodeRows rows, unsigned ro
       }
     }
   }
-  if (rawm) {  // raw frames: read as if interleaved (Q1), /32767, no window (Q2) - src/codec.rs:629-640
-#pragma unroll 1
-    for (int g = 0; g < G; ++g) {
-      if (!(rawm & (1u << g))) continue;
-      const unsigned r = (fr0 + g) * ch + c;
-      float *out = blocks + static_cast<size_t>(r) * kFrameI;
-      const unsigned long long raw_len = __shfl(rawlen_l, g);
-      const short *raw = rows.raw_pool + __shfl(raw_l, g);
-      for (int i = tid; i < kFrameI; i += 256) {
-        const unsigned long long si = static_cast<unsigned long long>(i) * ch + c;
-        float v = 0.0f;
-        if (si < raw_len) v = static_cast<float>(raw[si]) / 32767.0f;
-        out[i] = v;
-      }
-    }
-  }
   __syncthreads();
   // ascending union list: thread t owns bins 4t..4t+3; exclusive scan of the per-thread counts
   const unsigned nib = (s_mask[tid >> 3] >> ((tid & 7) * 4)) & 0xFu;
@@ -489,8 +475,43 @@ __global__ __launch_bounds__(256) void k_imdct_plan(DecodeRows rows, unsigned ro
 #pragma unroll
     for (int g = 0; g < G; ++g) total += n[g];
     const unsigned dense = n_u * G <= 2u * total ? 1u : 0u;
-    h[tid] = tid == 0 ? n_u : tid == 1 ? live : tid < 2 + ahead ? static_cast<unsigned>(s_u[tid - 2]) << 13 : tid == 6 ? dense : 0u;
+    // h[7]: rows of raw frames (written by the apply kernel: the plan may outlive one launch, the blocks do not)
+    h[tid] = tid == 0 ? n_u : tid == 1 ? live : tid < 2 + ahead ? static_cast<unsigned>(s_u[tid - 2]) << 13 : tid == 6 ? dense : tid == 7 ? rawm : 0u;
+    // work of the unit for the placement below: packed operations it issues (stored non-zeros) plus
+    // the per-entry overhead of walking its union (record fetch, table row)
+    if (tid == 0) plan_work[blockIdx.x] = total + n_u + (rawm ? 64u : 0u);
   }
+}
+
+// Placement of the units of one launch (speed only).  All units of a launch of <= 1024 are resident at
+// once, four to a CU, and the dispatcher deals an empty chip so that blocks b, b + 256, b + 512, b + 768
+// share a CU (measured: tools/d1_tune.hip prints the hardware ids).  The kernel ends when its slowest CU
+// does, so units are ranked by work (descending; ties by index, which makes the ranks a permutation)
+// and dealt in a snake over the 256 CU slots: heaviest with lightest.  Units beyond the first 1024
+// follow in descending order (they are dispatched as earlier ones finish: longest first).  One thread
+// per unit, every key compared from LDS; a few microseconds, amortised over the decodes that reuse the
+// plan (tools/d1_tune.hip: apply 80.4 -> 76.3 us at config 2).
+constexpr unsigned kOrderMaxUnits = 4096;
+__global__ __launch_bounds__(256) void k_imdct_order(const unsigned *__restrict__ plan_work, unsigned n_units,
+                                                      unsigned *__restrict__ order) {
+  __shared__ unsigned s_key[kOrderMaxUnits];
+  for (unsigned i = threadIdx.x; i < n_units; i += 256) s_key[i] = plan_work[i];
+  __syncthreads();
+  const unsigned u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= n_units) return;
+  const unsigned mine = s_key[u];
+  unsigned rank = 0;
+  for (unsigned j = 0; j < n_units; ++j) {
+    const unsigned k = s_key[j];
+    rank += (k > mine || (k == mine && j < u)) ? 1u : 0u;
+  }
+  unsigned pos = rank;
+  if (rank < 1024u) {
+    const unsigned round = rank >> 8, p = rank & 255u;
+    const unsigned in_round = min(256u, min(n_units, 1024u) - (round << 8));  // the last round may be partial
+    pos = (round << 8) + ((round & 1u) ? in_round - 1u - p : p);
+  }
+  order[pos] = u;
 }
 
 // rows (r, r+1) x 8 columns, coefficient pair in SGPRs: the same instruction block as k1::mac2rows
@@ -557,8 +578,9 @@ __device__ __forceinline__ void d1_mac2rows_fine_s(d1x2 (&c0)[4], d1x2 (&c1)[4],
 // measured and bought nothing: tools/d1_tune.hip, profiles/r02_d1_*).
 template <bool SKIP, bool PRIO = true, bool FINE = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void k_imdct_apply(DeviceTables tb, const unsigned *__restrict__ plan_hdr, const unsigned *__restrict__ plan_rec,
-                   unsigned n_frames, unsigned ch, unsigned group_begin, unsigned n_units, float *__restrict__ blocks) {
+void k_imdct_apply(DeviceTables tb, DecodeRows rows, unsigned row_begin, const unsigned *__restrict__ plan_hdr,
+                   const unsigned *__restrict__ plan_rec, const unsigned *__restrict__ order, unsigned n_frames, unsigned ch,
+                   unsigned group_begin, unsigned n_units, float *__restrict__ blocks) {
   constexpr int G = 8, R = 2;
   // block -> unit (frame group, channel) of this batch.  (Speed only.)  All units of a launch of
   // <= 1024 are resident at once, four to a CU, and the dispatcher deals an empty chip so that blocks
@@ -568,14 +590,41 @@ void k_imdct_apply(DeviceTables tb, const unsigned *__restrict__ plan_hdr, const
   // channel whenever 256 % ch == 0 - leaves the slowest CU 14 % above the mean; rotating the channel
   // by the round (b / 256) of the frame group's first block gives every CU all channels (7 % above;
   // a full sort by work would reach 4 % but costs more than it returns: 10 us in the plan kernel).
-  const unsigned fg = blockIdx.x / ch;
-  const unsigned c = (blockIdx.x - fg * ch + ((fg * ch) >> 8)) % ch;
+  // ... or, when the launch has been ranked by work (k_imdct_order), the table says which unit this block takes.
   if (blockIdx.x >= n_units) return;
+  unsigned fg, c;
+  if (order) {
+    const unsigned u = __builtin_amdgcn_readfirstlane(order[blockIdx.x]);
+    fg = u / ch;
+    c = u - fg * ch;
+  } else {
+    fg = blockIdx.x / ch;
+    c = (blockIdx.x - fg * ch + ((fg * ch) >> 8)) % ch;
+  }
   const unsigned local = fg * ch + c;
   const unsigned fr0 = (group_begin + fg) * G;
   const unsigned *hdr = plan_hdr + static_cast<size_t>(local) * kPlanHdrDwords;
   const unsigned n_u = __builtin_amdgcn_readfirstlane(hdr[0]);
   const unsigned live = __builtin_amdgcn_readfirstlane(hdr[1]);
+  const unsigned rawm = __builtin_amdgcn_readfirstlane(hdr[7]);
+  if (rawm) {  // raw frames: read as if interleaved (Q1), /32767, no window (Q2) - src/codec.rs:629-640
+#pragma unroll 1
+    for (int g = 0; g < G; ++g) {
+      if (!(rawm & (1u << g))) continue;
+      const unsigned r = (fr0 + g) * ch + c;
+      const unsigned m = row_begin + r;
+      float *out = blocks + static_cast<size_t>(r) * kFrameI;
+      const unsigned long long raw_len = rows.row_raw_len[m];
+      const short *raw = rows.raw_pool + rows.row_raw[m];
+#pragma unroll 1
+      for (int i = threadIdx.x; i < kFrameI; i += 256) {
+        const unsigned long long si = static_cast<unsigned long long>(i) * ch + c;
+        float v = 0.0f;
+        if (si < raw_len) v = static_cast<float>(raw[si]) / 32767.0f;
+        out[i] = v;
+      }
+    }
+  }
   if (!live) return;
   // The four waves of a SIMD are arbitrated oldest-first, so left alone they finish one after the
   // other and the last one runs by itself, with nobody to fill its scalar and wait slots.  Each wave
@@ -965,12 +1014,13 @@ hipError_t launch_compact(const uint8_t *records, uint32_t M, uint32_t ch, uint6
 }
 
 uint64_t imdct_plan_bytes(uint32_t groups) {
-  return static_cast<uint64_t>(groups) * (4ull * kPlanHdrDwords + static_cast<uint64_t>(kPlanRecCap) * kPlanRecDwords * 4ull);
+  // headers | records | work keys | unit order
+  return static_cast<uint64_t>(groups) * (4ull * kPlanHdrDwords + static_cast<uint64_t>(kPlanRecCap) * kPlanRecDwords * 4ull + 8ull);
 }
 
 hipError_t launch_imdct_rows(const DeviceTables &t, const DecodeRows &rows, uint32_t row_begin,
                              uint32_t M, uint32_t ch, float *blocks, hipStream_t s, int variant, void *plan,
-                             uint32_t plan_groups) {
+                             uint32_t plan_groups, bool reuse_plan) {
   if (M == 0) return hipSuccess;
   // every caller decodes whole frames; the one-row kernel is the cross-check variant (glc_debug.h)
   if (variant == 1 || ch == 0 || M % ch != 0) {
@@ -984,20 +1034,29 @@ hipError_t launch_imdct_rows(const DeviceTables &t, const DecodeRows &rows, uint
   // plan_groups (frame group, channel) units
   unsigned *hdr = static_cast<unsigned *>(plan);
   unsigned *rec = hdr + static_cast<size_t>(plan_groups) * kPlanHdrDwords;
+  unsigned *work = rec + static_cast<size_t>(plan_groups) * kPlanRecCap * kPlanRecDwords;
+  unsigned *order = work + plan_groups;
   const uint32_t fg_per_batch = plan_groups / ch;
+  if (reuse_plan && groups > fg_per_batch) return hipErrorInvalidValue;  // only a one-batch launch leaves its plan behind
   for (uint32_t fg0 = 0; fg0 < groups; fg0 += fg_per_batch) {
     const uint32_t n_fg = groups - fg0 < fg_per_batch ? groups - fg0 : fg_per_batch;
     const uint32_t n_units = n_fg * ch;
     const dim3 grid(n_units);
-    hipLaunchKernelGGL(k_imdct_plan, grid, dim3(256), 0, s, rows, row_begin, n_frames, ch, fg0, 2u, hdr, rec, blocks);
+    // more units than CUs: rank them by work (fewer land one per CU whatever the order)
+    const bool ranked = n_units > 256 && n_units <= kOrderMaxUnits;
+    if (!reuse_plan) {
+      hipLaunchKernelGGL(k_imdct_plan, grid, dim3(256), 0, s, rows, row_begin, n_frames, ch, fg0, 2u, hdr, rec, work);
+      if (ranked) hipLaunchKernelGGL(k_imdct_order, dim3((n_units + 255) / 256), dim3(256), 0, s, work, n_units, order);
+    }
+    const unsigned *ord = ranked ? order : nullptr;
     if (variant == 2)
-      hipLaunchKernelGGL(k_imdct_apply<false>, grid, dim3(256), 0, s, t, hdr, rec, n_frames, ch, fg0, n_units, blocks);
+      hipLaunchKernelGGL(k_imdct_apply<false>, grid, dim3(256), 0, s, t, rows, row_begin, hdr, rec, ord, n_frames, ch, fg0, n_units, blocks);
     else if (variant == 4)
-      hipLaunchKernelGGL((k_imdct_apply<true, true, false>), grid, dim3(256), 0, s, t, hdr, rec, n_frames, ch, fg0, n_units, blocks);
+      hipLaunchKernelGGL((k_imdct_apply<true, true, false>), grid, dim3(256), 0, s, t, rows, row_begin, hdr, rec, ord, n_frames, ch, fg0, n_units, blocks);
     else if (variant == 3)
-      hipLaunchKernelGGL((k_imdct_apply<true, false>), grid, dim3(256), 0, s, t, hdr, rec, n_frames, ch, fg0, n_units, blocks);
+      hipLaunchKernelGGL((k_imdct_apply<true, false>), grid, dim3(256), 0, s, t, rows, row_begin, hdr, rec, ord, n_frames, ch, fg0, n_units, blocks);
     else
-      hipLaunchKernelGGL(k_imdct_apply<true>, grid, dim3(256), 0, s, t, hdr, rec, n_frames, ch, fg0, n_units, blocks);
+      hipLaunchKernelGGL(k_imdct_apply<true>, grid, dim3(256), 0, s, t, rows, row_begin, hdr, rec, ord, n_frames, ch, fg0, n_units, blocks);
   }
   return hipGetLastError();
 }

@@ -242,6 +242,95 @@ int glc_frame_scale(const glc_frames *f, uint64_t frame, uint32_t channel, float
 /* EncodedFrame.raw_pcm: copies up to cap samples, returns the length through n. */
 int glc_frame_raw(const glc_frames *f, uint64_t frame, int16_t *pcm, uint64_t cap, uint64_t *n);
 
+/* ---- EncodedAudio as flat arrays: the structured bridge to the reference's nested Vecs ------- */
+
+/* EncodedAudio (src/codec.rs:31-69) as the flat pools a glc_frames keeps, so that a host fills or
+ * reads `Vec<EncodedFrame>` with one slice copy per list and no byte stream in between.  Every Vec of
+ * the schema keeps its own length (any well-formed .glc round-trips):
+ *   frame f: sparse_coeffs_per_channel = lists  list_begin[f] .. list_begin[f+1]   (indices into list_off)
+ *            list l                    = pairs  list_off[l]   .. list_off[l+1]     ((u16 index, i16 value),
+ *                                        4 bytes each: index in the low half, the layout of src/codec.rs:303-306
+ *                                        written little-endian - what bincode emits for Vec<(u16, i16)>)
+ *            scale_factors             = scales scale_begin[f] .. scale_begin[f+1]
+ *            raw_pcm                   = None if raw_tag[f] == 0, else raw raw_begin[f] .. raw_begin[f+1]
+ * As a VIEW (glc_frames_get_view) the pointers are borrowed from the glc_frames and stay valid until it
+ * is freed.  As PARTS (glc_frames_from_parts) they are the caller's arrays, copied by the call. */
+typedef struct glc_frames_view {
+  uint32_t sample_rate;     /* AudioHeader, src/codec.rs:39-46 */
+  uint16_t channels;
+  uint16_t reserved;
+  uint64_t total_samples;
+  uint32_t encoder_delay;   /* GaplessInfo, src/codec.rs:48-53 */
+  uint32_t padding;
+  uint64_t original_length;
+  uint64_t n_frames;
+  uint64_t n_lists;         /* all sparse lists of the stream */
+  uint64_t n_pairs;
+  uint64_t n_scales;
+  uint64_t n_raw;           /* i16 samples in the raw pool */
+  const uint64_t *list_begin;   /* [n_frames + 1] */
+  const uint64_t *list_off;     /* [n_lists + 1]  */
+  const uint32_t *pairs;        /* [n_pairs]      */
+  const uint64_t *scale_begin;  /* [n_frames + 1] */
+  const float *scales;          /* [n_scales]     */
+  const uint8_t *raw_tag;       /* [n_frames]     */
+  const uint64_t *raw_begin;    /* [n_frames + 1] */
+  const int16_t *raw;           /* [n_raw]        */
+} glc_frames_view;
+
+/* Borrow the pools of `f` (≙ reading the EncodedAudio that Encoder::encode returned, src/codec.rs:421). */
+int glc_frames_get_view(const glc_frames *f, glc_frames_view *out);
+
+/* Build an EncodedAudio from flat arrays (≙ the `&EncodedAudio` Decoder::decode takes, src/codec.rs:744).
+ * Every offset is validated (monotonic, inside its pool); GLC_EFORMAT otherwise.  `stream_id`: 0, or a
+ * caller-chosen identity < 2^63 of this stream's CONTENT - the caller promises that two objects built
+ * with the same non-zero id hold the same stream.  A context recognises the id of the stream whose
+ * sparse rows (and inverse-transform plan) it still holds on the device and decodes it again without
+ * preparing or uploading anything (glc_ctx_resident_stream). */
+int glc_frames_from_parts(const glc_frames_view *parts, uint64_t stream_id, glc_frames **out);
+
+/* The same constructor for a host whose lists live in separate allocations (the reference's
+ * Vec<Vec<(u16, i16)>>): pointer + length per list, per-frame scale and raw vectors by pointer; the
+ * payload is copied once, straight into the pools.  list l of frame f is lists[Σ_{g<f} lists_per_frame[g] + l]. */
+typedef struct glc_frames_gather {
+  uint32_t sample_rate;
+  uint16_t channels;
+  uint16_t reserved;
+  uint64_t total_samples;
+  uint32_t encoder_delay;
+  uint32_t padding;
+  uint64_t original_length;
+  uint64_t n_frames;
+  const uint32_t *lists_per_frame;   /* [n_frames]                sparse_coeffs_per_channel.len() */
+  const void *const *list_ptr;       /* [Σ lists_per_frame]       pointer to the list's 4-byte pairs */
+  const uint32_t *list_len;          /* [Σ lists_per_frame]       pairs in the list */
+  const uint32_t *scales_per_frame;  /* [n_frames]                scale_factors.len() */
+  const float *const *scale_ptr;     /* [n_frames] */
+  const int16_t *const *raw_ptr;     /* [n_frames]                NULL = raw_pcm: None */
+  const uint64_t *raw_len;           /* [n_frames] */
+} glc_frames_gather;
+int glc_frames_from_gather(const glc_frames_gather *g, uint64_t stream_id, glc_frames **out);
+
+/* Identity of a glc_frames: the stream_id it was built with (glc_frames_from_parts / _gather), or a
+ * process-unique number >= 2^63 for objects the library built itself. */
+uint64_t glc_frames_stream_id(const glc_frames *f);
+/* Identity of the stream whose sparse rows `ctx` holds on the device (0: none). */
+uint64_t glc_ctx_resident_stream(const glc_ctx *ctx);
+/* Decoder::decode of the resident stream, without a glc_frames: for a host that has recognised the
+ * stream by its id and so need not flatten its nested vectors again.  GLC_EINVAL if `stream_id` is not
+ * the resident stream (then build the glc_frames and call glc_decode). */
+int glc_decode_resident(glc_ctx *ctx, uint64_t stream_id, float *pcm_out, uint64_t cap, uint64_t *n_out);
+
+/* Encoder::encode with a hook: `fn(user, view, frame_begin, frame_end)` is called on the calling thread
+ * each time the frames [frame_begin, frame_end) have arrived on the host (ranges ascend and tile
+ * [0, n_frames)), while the device still works on later frames - where a host builds its nested
+ * EncodedFrame vectors, hidden behind the rest of the encode instead of after it.  `view` covers
+ * frames [0, frame_end) and is valid only during the call.  A non-zero return aborts the encode
+ * (GLC_EINVAL).  `out` may be NULL when the hook has taken everything it needs. */
+typedef int (*glc_frames_hook)(void *user, const glc_frames_view *view, uint64_t frame_begin, uint64_t frame_end);
+int glc_encode_hooked(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t channels,
+                      glc_frames_hook fn, void *user, glc_frames **out);
+
 /* ---- WAV file I/O twin (src/audio.rs; host only, no device) ---------------------------------- */
 
 /* load_wav src/audio.rs:39-64: RIFF/WAVE PCM (8/16/24/32-bit integer -> s / 2^(bits-1), 8-bit is
