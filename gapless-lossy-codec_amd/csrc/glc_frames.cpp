@@ -68,7 +68,9 @@ uint64_t next_frames_uid() {
 }
 
 // Index vectors of EncodedAudio for the frames of ONE compact blob whose payload (pairs, raw planes)
-// already sits in F->pairs / F->raw at p_at / r_at: per-frame raw tags, list offsets, scales.  `meta`
+// already sits in F->pairs / F->raw at p_at / r_at: per-frame raw tags, list offsets, scales.  Appends
+// to F->list_off (which starts as {0}: every list adds its end offset, so the vector is complete after
+// every blob - glc_encode_hooked hands out views of a stream that is still growing) and F->scales.  `meta`
 // points at the blob's first o_pairs bytes (header + raw flags + scales + counts).  Untrusted blobs
 // are checked for canonical (strictly ascending, < 1024) lists on the way.
 int index_compact_meta(glc_frames *F, uint32_t ch, const CompactHeader &h, const uint8_t *meta, uint64_t f_at,
@@ -107,12 +109,12 @@ int index_compact_meta(glc_frames *F, uint32_t ch, const CompactHeader &h, const
             last = k;
           }
         }
-        F->list_off.push_back(p_at + p_in);
-        F->scales.push_back(scale[f * ch + c]);
         p_in += n;
+        F->list_off.push_back(p_at + p_in);  // list_off = {0, end of list 0, end of list 1, ...}: the caller pushed the 0
+        F->scales.push_back(scale[f * ch + c]);
       }
     }
-    F->list_begin[fo + 1] = F->list_off.size();
+    F->list_begin[fo + 1] = F->list_off.size() - 1;  // lists so far (list_off carries a leading 0)
     F->scale_begin[fo + 1] = F->scales.size();
     F->raw_begin[fo + 1] = r_at + raw_rows_in * kFrame;
   }
@@ -190,6 +192,7 @@ int frames_from_compact(uint32_t sample_rate, uint64_t n_samples, uint16_t chann
     const uint64_t n_comp_rows = n_frames * ch - n_raw_rows;
     F->list_off.clear();
     F->list_off.reserve(n_comp_rows + 1);
+    F->list_off.push_back(0);
     F->scales.clear();
     F->scales.reserve(n_comp_rows);
     uint64_t f_at = 0, p_at = 0, r_at = 0;  // frames / pairs / raw samples placed so far
@@ -207,7 +210,6 @@ int frames_from_compact(uint32_t sample_rate, uint64_t n_samples, uint16_t chann
       p_at += h.n_pairs;
       r_at += h.n_raw_rows * kFrame;
     }
-    F->list_off.push_back(n_pairs);
   } catch (const std::bad_alloc &) {
     return GLC_ENOMEM;
   }

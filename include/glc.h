@@ -321,12 +321,14 @@ uint64_t glc_ctx_resident_stream(const glc_ctx *ctx);
  * the resident stream (then build the glc_frames and call glc_decode). */
 int glc_decode_resident(glc_ctx *ctx, uint64_t stream_id, float *pcm_out, uint64_t cap, uint64_t *n_out);
 
-/* Encoder::encode with a hook: `fn(user, view, frame_begin, frame_end)` is called on the calling thread
- * each time the frames [frame_begin, frame_end) have arrived on the host (ranges ascend and tile
- * [0, n_frames)), while the device still works on later frames - where a host builds its nested
- * EncodedFrame vectors, hidden behind the rest of the encode instead of after it.  `view` covers
- * frames [0, frame_end) and is valid only during the call.  A non-zero return aborts the encode
- * (GLC_EINVAL).  `out` may be NULL when the hook has taken everything it needs. */
+/* Encoder::encode with a hook: `fn(user, view, frame_begin, frame_end)` is called each time the frames
+ * [frame_begin, frame_end) have arrived on the host (ranges ascend and tile [0, n_frames)), while the
+ * device still works on later frames - where a host builds its nested EncodedFrame vectors, hidden
+ * behind the rest of the encode instead of after it.  The calls are made on the calling thread, in the
+ * time it would otherwise spend blocked on the device (ranges of a few dozen frames while it polls,
+ * the remainder at the end).  `view` covers frames [0, frame_end) and is valid only during the call.
+ * A non-zero return aborts the encode (GLC_EINVAL).  `out` may be NULL when the hook has taken
+ * everything it needs. */
 typedef int (*glc_frames_hook)(void *user, const glc_frames_view *view, uint64_t frame_begin, uint64_t frame_end);
 int glc_encode_hooked(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16_t channels,
                       glc_frames_hook fn, void *user, glc_frames **out);

@@ -150,7 +150,7 @@ GPU_CASES = [
     ("cfg1_sine_44k_stereo", lambda: gen_tone("sine", 440.0, 44100, 2, 2.0), 44100, 2),
     ("noise_raw_44k_stereo", lambda: gen_noise(44100, 2, 0.4, 12345), 44100, 2),
     ("mixed_3ch", lambda: np.concatenate([gen_chord(44100, 3, 30000), gen_noise(44100, 3, 0.3, 5), gen_chord(44100, 3, 9000)]), 44100, 3),
-    ("chord_48k_stereo_5_rounds", lambda: gen_chord(48000, 2, 1024 * 4500), 48000, 2),
+    ("chord_48k_stereo_5_rounds", lambda: gen_chord(48000, 2, 1024 * 4700), 48000, 2),
 ]
 
 
@@ -185,15 +185,21 @@ def test_encode_hooked_delivers_the_stream_in_ascending_ranges(torch_cuda, name,
 
     def hook(parts, f0, f1):
         seen.append((f0, f1))
-        assert parts["n_frames"] == f1 and parts["list_begin"].size == f1 + 1
+        assert parts["n_frames"] == f1 and parts["list_begin"].size == f1 + 1, (parts["n_frames"], f0, f1)
         sub = nested_from_parts(parts)
         nested.extend(sub[f0:f1])
         return 0
     ea = enc.encode_hooked(x, ch, hook)
     n_frames = ea.info().n_frames
     assert seen[0][0] == 0 and seen[-1][1] == n_frames and all(a[1] == b[0] for a, b in zip(seen, seen[1:]))
-    if n_frames > 4096:
-        assert len(seen) >= 5, "a stream of several rounds arrives round by round"
+    # (how many ranges a stream of several rounds arrives in depends on how far the device is ahead of the
+    # host: a cold first call delivers everything at the end, a warm one in slices of a few dozen frames
+    # while it waits - tools/bridge_bench.cpp checks that case)
+    for _ in range(3):
+        seen.clear(), nested.clear()
+        ea = enc.encode_hooked(x, ch, hook)
+        assert seen[0][0] == 0 and seen[-1][1] == n_frames and all(a[1] == b[0] for a, b in zip(seen, seen[1:]))
+        assert EncodedAudio.from_nested(ea.header, nested, ea.gapless_info).to_bytes() == ref.glc
     assert ea.to_bytes() == ref.glc
     assert EncodedAudio.from_nested(ea.header, nested, ea.gapless_info).to_bytes() == ref.glc
     # a hook that says stop: GLC_EINVAL, and the context stays usable
@@ -216,7 +222,7 @@ def test_stream_id_keeps_rows_and_plan_resident(torch_cuda):
     torch = torch_cuda
     sr, ch = 44100, 2
     x = np.concatenate([gen_chord(sr, ch, 40000), gen_noise(sr, ch, 0.3, 5), gen_chord(sr, ch, 20000, seed=3)])
-    ref = O.encode(x, sr, ch)
+    ref = O.encode(x, sr, ch, taps=True)
     assert 0 < ref.is_raw.sum() < ref.n_frames
     dref, _, _ = O.decode(ref.glc)
     p = EncodedAudio.from_bytes(ref.glc).parts()
