@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import calculate_snr, gen_noise, gen_tone, parse_glc
+from conftest import ROOT, calculate_snr, gen_noise, gen_tone, parse_glc
 from oracle import glc_oracle_np as NP
 from oracle import oracle as O
 
@@ -163,3 +163,30 @@ def _golden_input(case):
     if g["kind"] == "noise":
         return gen_noise(case["sample_rate"], case["channels"], g["dur"], g["seed"])
     return gen_tone(g["kind"], g["f0"], case["sample_rate"], case["channels"], g["dur"], g.get("f1", 0.0))
+
+
+def test_faster_transforms_change_the_bitstream():
+    """SURVEY F2 / F3, reproducible from the repo (tools/f2_evidence.py; numbers quoted in DESIGN.md
+    section 2): the north_star's butterfly / FFT MDCT converges to the TRUE cosine transform, the
+    reference evaluates an f32 table of cosf(f32-rounded angle) with separately rounded multiply and
+    add in ascending order (src/codec.rs:326-338, :359-374).  Feeding the oracle's own scale /
+    threshold / quantiser (src/codec.rs:188-311) with the true-cosine coefficients, with an FMA chain
+    over the reference's table, or with the smallest re-association (two accumulators) changes
+    scale-factor bits - which the .glc stores verbatim - and quantised integers.  None of them can
+    produce the reference's bytes; that is why K1 is an exact-order contraction."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import f2_evidence as F2
+    seen = {}
+    for name, x, sr, ch in F2.signals():
+        seen[name] = F2.compare(x, sr, ch)
+    sine, noise = seen["cfg1_sine440_44k_stereo_2s"], seen["lcg_noise_44k_stereo_1s"]
+    # the ideal transform: every scale factor differs, on both signals; broadband content loses most integers
+    assert sine["true_cosine_f64"]["scale_bits_differing"] == 1.0 and noise["true_cosine_f64"]["scale_bits_differing"] == 1.0
+    assert sine["true_cosine_f64"]["quantised_ints_differing"] > 0.005
+    assert noise["true_cosine_f64"]["quantised_ints_differing"] > 0.5 and noise["true_cosine_f64"]["max_abs_q_delta"] > 9
+    # same table, fused or re-associated: still not the reference's stream
+    for v in ("fused_f32", "split_k2_f32"):
+        for s in (sine, noise):
+            assert s[v]["scale_bits_differing"] > 0.25, (v, s[v])
+            assert s[v]["quantised_ints_differing"] > 0.0, (v, s[v])
