@@ -244,13 +244,27 @@ def main():
         enc.mdct_forward_device(d_pcm.data_ptr(), me.t0, me.t_count, n_samples, CH, me.frame_begin,
                                 me.frame_end, d_coef.data_ptr())
 
+    import ctypes as C
+    L = glc_amd.lib
+    L.glc_debug_clock_probe_begin.restype = C.c_int
+    L.glc_debug_clock_probe_begin.argtypes = [C.c_void_p, C.c_uint32]
+    L.glc_debug_clock_probe_end.restype = C.c_int
+    L.glc_debug_clock_probe_end.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     for _ in range(10):
         step()
     k1()
+    # the clock the chip HOLDS under this kernel: one sleeping wave reads the shader-cycle counter against
+    # the 100 MHz reference over ~60 % of the timed launches (include/glc_debug.h; measurement only)
+    probe_ok = L.glc_debug_clock_probe_begin(enc._h, int(0.6 * k1_reps * 550)) == 0
     enc.timer_begin()          # HIP events on the stream the kernels are launched on
     for _ in range(k1_reps):
         k1()
     k1_ms = enc.timer_end() / k1_reps
+    k1_clock_ghz = None
+    if probe_ok:
+        g = C.c_float()
+        if L.glc_debug_clock_probe_end(enc._h, C.byref(g)) == 0 and 0.3 < g.value < 3.5:
+            k1_clock_ghz = float(g.value)
     enc.timer_begin()          # whole step with events too (profile cross-check)
     for _ in range(k1_reps):
         step()
@@ -262,31 +276,47 @@ def main():
 
     # ---- the north_star's 44.1 / 96 kHz variants of the same batch (only the band tables of the
     # quantiser depend on the rate; reported beside the headline, never as `value`) ------------
-    other_rates = None
-    if world == 1:
-        other_rates = {}
-        for sr2 in (44100, 96000):
-            e2 = glc_amd.Encoder(sr2, device=local_rank)
-            reps = max(10, min(args.steps, 50))
-            for _ in range(args.spinup):  # the device clocked down while the host built this rate's tables
-                e2.encode_range_device(d_pcm.data_ptr(), me.t0, me.t_count, n_samples, CH, me.frame_begin,
-                                       me.frame_end, d_rec.data_ptr())
-            e2.timer_begin()
-            for _ in range(reps):
-                e2.encode_range_device(d_pcm.data_ptr(), me.t0, me.t_count, n_samples, CH, me.frame_begin,
-                                       me.frame_end, d_rec.data_ptr())
-            ms = e2.timer_end() / reps
-            other_rates[str(sr2)] = {"Msamples/s": round(FRAMES_PER_GPU * HOP * CH / (ms * 1e-3) / 1e6, 1),
-                                     "ms_per_step_events": round(ms, 4)}
-            e2.close()
-        # restore the 48 kHz records for the checks below
-        step()
-        enc.synchronize()
+    other_rates = {}
+    for sr2 in (44100, 96000):
+        e2 = glc_amd.Encoder(sr2, device=local_rank)
+        reps = max(10, min(args.steps, 50))
+        for _ in range(args.spinup):  # the device clocked down while the host built this rate's tables
+            e2.encode_range_device(d_pcm.data_ptr(), me.t0, me.t_count, n_samples, CH, me.frame_begin,
+                                   me.frame_end, d_rec.data_ptr())
+        e2.timer_begin()
+        for _ in range(reps):
+            e2.encode_range_device(d_pcm.data_ptr(), me.t0, me.t_count, n_samples, CH, me.frame_begin,
+                                   me.frame_end, d_rec.data_ptr())
+        ms = e2.timer_end() / reps
+        ms_all = [ms]
+        if dist_on:  # every rank times its own shard; the job's rate is all samples over the slowest rank
+            tt = torch.tensor([ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            gl = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(gl, tt)
+            ms_all = [float(t.item()) for t in gl]
+        other_rates[str(sr2)] = {"Msamples/s": round(FRAMES_PER_GPU * HOP * CH * world / (max(ms_all) * 1e-3) / 1e6, 1),
+                                 "ms_per_step_events": round(max(ms_all), 4),
+                                 "ms_per_step_events_min_over_ranks": round(min(ms_all), 4)}
+        e2.close()
+    # restore the 48 kHz records for the checks below
+    step()
+    enc.synchronize()
+    # K1's event time and held clock on every rank (min / max over ranks)
+    k1_ranks = None
+    if dist_on:
+        tt = torch.tensor([k1_ms, k1_clock_ghz or 0.0], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        gl = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(gl, tt)
+        ks = [float(t[0].item()) for t in gl]
+        cs = [float(t[1].item()) for t in gl if float(t[1].item()) > 0]
+        k1_ranks = {"ms_per_launch_min": round(min(ks), 4), "ms_per_launch_max": round(max(ks), 4),
+                    "clock_ghz_min": round(min(cs), 3) if cs else None, "clock_ghz_max": round(max(cs), 3) if cs else None}
 
     # ---- sanity: records of this run assemble into a valid stream (rank 0, own shard) ----
     encoded = None
-    if rank == 0 and world == 1:
-        ea = glc_amd.EncodedAudio.from_records(SR, n_samples, CH, d_rec.cpu().numpy())
+    if rank == 0:
+        # (rank 0's 4096 records, indexed as a stream of their own: the bookkeeping below is per GPU)
+        ea = glc_amd.EncodedAudio.from_records(SR, FRAMES_PER_GPU * HOP * CH, CH, d_rec.cpu().numpy())
         i = ea.info()
         cinfo = enc.compact_device_records(d_rec.data_ptr(), me.n_frames, CH, d_blob.data_ptr(), blob_cap)
         encoded = {"n_frames": int(i.n_frames), "raw_frames": int(i.n_raw_frames), "total_nnz": int(i.total_nnz),
@@ -296,7 +326,7 @@ def main():
     # ---- PCIe-inclusive host boundary (Encoder::encode from host memory + save_encoded bytes);
     # reported beside the headline, never as `value` -------------------------------------------
     host_boundary = None
-    if rank == 0 and world == 1:
+    if rank == 0:
         best = None
         ea_h = blob = None
         for _ in range(60):  # the device clocked down while the records came back to the host: 75 ms of the same call
@@ -312,23 +342,45 @@ def main():
             h1 = time.perf_counter()
             blob = ea_h.to_bytes()
             h2 = time.perf_counter()
-            if best is None or h1 - h0 < best[0]:
-                best = (h1 - h0, h2 - h1, len(blob))
+            if best is None:
+                best = [h1 - h0, h2 - h1, len(blob)]
+            best[0] = min(best[0], h1 - h0)   # each leg its own best-of
+            best[1] = min(best[1], h2 - h1)
         pcm_bytes = pcm_host.size * 4
+        # the same call through the reference's own data model (nested vectors): tools/bridge_bench.cpp, a
+        # C++ process of its own driving the structured bridge of include/glc.h like the Rust shim of
+        # INTEGRATION.md section 3 would; this process is idle meanwhile
+        shim = None
+        exe = os.path.join(ROOT, "build", "bridge_bench")
+        if os.path.exists(exe):
+            try:
+                np.asarray(pcm_host[:FRAMES_PER_GPU * HOP * CH]).tofile(os.path.join(ROOT, "build", "chord_cfg2.f32"))
+                r = subprocess.run([exe, str(FRAMES_PER_GPU), str(CH), str(SR)], cwd=ROOT, capture_output=True, text=True, timeout=300)
+                for ln in r.stdout.splitlines():
+                    if ln.startswith("summary_json "):
+                        shim = json.loads(ln[len("summary_json "):])
+                if shim is None:
+                    shim = {"error": (r.stdout + r.stderr)[-300:]}
+            except Exception as e:  # noqa: BLE001 - a measurement beside the headline must not fail the bench
+                shim = {"error": repr(e)}
         host_boundary = {"encode_ms": round(best[0] * 1e3, 3), "serialize_ms": round(best[1] * 1e3, 3),
                          "Msamples/s": round(FRAMES_PER_GPU * HOP * CH / best[0] / 1e6, 1), "glc_bytes": best[2],
                          "h2d_bytes": int(pcm_bytes),
                          "pcie_gen5_x16_GBs": 63.0,
                          "h2d_floor_ms_at_pcie_peak": round(pcm_bytes / 63.0e9 * 1e3, 3),
-                         "note": "host f32 PCM (pageable, caller-owned) -> two half-batch rounds through a three-thread "
-                                 "pipeline: round 2 goes up under round 1's kernels, round 1's compact blob comes down and "
-                                 "is indexed under round 2's; the payload lands in the EncodedAudio pools directly; best of 8"}
+                         "shim_equivalent": shim,
+                         "note": "host f32 PCM (pageable, caller-owned) -> four 1024-frame rounds on two streams through a "
+                                 "three-thread pipeline: round i+1 goes up under round i's kernels, round i-1's compact blob "
+                                 "comes down and is indexed meanwhile; the payload lands in the EncodedAudio pools directly; "
+                                 "encode_ms and serialize_ms are each the best of 8.  shim_equivalent: the calls a Rust "
+                                 "Encoder::encode / Decoder::decode make through the structured bridge, with the "
+                                 "EncodedAudio as nested vectors on the host side (tools/bridge_bench.cpp)"}
 
     # ---- decode of the same batch, device-resident (sparse rows resident -> interleaved PCM in
     # HBM): D1 sparse IMDCT + window, D2 overlap-add.  Beside the headline, never `value`. ---------
     decode = None
-    if rank == 0 and world == 1:
-        ea_d = glc_amd.EncodedAudio.from_records(SR, n_samples, CH, d_rec.cpu().numpy())
+    if rank == 0:
+        ea_d = glc_amd.EncodedAudio.from_records(SR, FRAMES_PER_GPU * HOP * CH, CH, d_rec.cpu().numpy())
         dec = glc_amd.Decoder(CH, SR, device=local_rank)
         d_all = torch.empty((FRAMES_PER_GPU + 1) * HOP * CH, dtype=torch.float32, device="cuda")
         d_blk = torch.empty((FRAMES_PER_GPU * CH, 2048), dtype=torch.float32, device="cuda")
@@ -371,9 +423,9 @@ def main():
 
     # ---- CPU baseline: the oracle (a port of src/codec.rs) on this box's cores, rank 0, N=1
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         from oracle import oracle as O  # checker/baseline only — never on the product path
-        cores = min(16, os.cpu_count() or 1)  # a one-GPU box's CPU share is 16 cores
+        cores = min(16, os.cpu_count() or 1)  # a one-GPU box's CPU share is 16 cores (the other ranks idle in the barrier below)
         nfr = FRAMES_PER_GPU  # the full cfg2 batch, timed twice (~15 core-seconds of CPU work)
         sec = min(O.time_encode_frames(pcm_host, SR, CH, 0, nfr, n_threads=cores) for _ in range(2))
         cpu = {"value": round(nfr * HOP * CH / sec / 1e6, 3), "unit": "Msamples/s", "cores": cores,
@@ -394,7 +446,10 @@ def main():
         except Exception:
             traffic = None
 
+    if dist_on:
+        dist.barrier()   # rank 0's single-rank legs (decode, host boundary, CPU baseline) are done
     if rank == 0:
+        k1_peak_held = F32_PEAK_TFLOPS * k1_clock_ghz / 2.4 if k1_clock_ghz else None
         out = {
             "metric": "Msamples/s encoded (48 kHz stereo batch) at 1/2/4/8 GPUs; % HBM roofline",
             "value": round(value, 2),
@@ -419,12 +474,21 @@ def main():
                          "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(k1_tflops / F32_PEAK_TFLOPS, 4),
                          "frac_of_unfused_ceiling": round(k1_tflops / F32_UNFUSED_TFLOPS, 4),
+                         "clock_ghz_held": round(k1_clock_ghz, 3) if k1_clock_ghz else None,
+                         "peak_at_held_clock": round(k1_peak_held, 1) if k1_peak_held else None,
+                         "frac_at_held_clock": round(k1_tflops / k1_peak_held, 4) if k1_peak_held else None,
+                         "frac_of_unfused_ceiling_at_held_clock": round(2.0 * k1_tflops / k1_peak_held, 4) if k1_peak_held else None,
                          "traffic": traffic, "traffic_source": traffic_source,
-                         "ms_per_launch": round(k1_ms, 4),
-                         "note": "f32 vector-ALU issue roofline (157.3 TFLOP/s counts an FMA as 2 flop); 4096 "
+                         "traffic_is": "bytes that missed the XCD L2s (FETCH_SIZE x 2 + WRITE_SIZE per launch, counters calibrated "
+                                       "on known byte counts); the 16 MiB working set of a step is Infinity-Cache resident, so "
+                                       "these are L2-fabric bytes, an upper bound on HBM bytes",
+                         "ms_per_launch": round(k1_ms, 4), "per_rank": k1_ranks,
+                         "note": "f32 vector-ALU issue roofline (157.3 TFLOP/s at 2.4 GHz counts an FMA as 2 flop); 4096 "
                                  "flop/sample = 2048 separately rounded mul + 2048 add.  Bit-exact parity forbids "
                                  "FMA and MFMA accumulation, so the ceiling of this kernel is 78.65 TFLOP/s "
-                                 "(frac_of_unfused_ceiling)."},
+                                 "(frac_of_unfused_ceiling).  clock_ghz_held: shader clock measured in-kernel beside "
+                                 "these launches (s_memtime / s_memrealtime); the *_at_held_clock fractions scale "
+                                 "the peak by it."},
             "roofline_hbm": {"bound": "hbm", "achieved": round(k1_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(k1_gbs / HBM_PEAK_GBS, 5), "pct_hbm_roofline": round(100 * k1_gbs / HBM_PEAK_GBS, 3),
                              "note": "BASELINE metric's '% HBM roofline': 6.006 algorithmic B/sample; the "

@@ -172,12 +172,14 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
         "(or `make -C gapless-lossy-codec_amd/csrc`).  There is no CPU fallback.")
 
-# PyTorch's ROCm wheel bundles its own HIP + HSA runtimes.  If torch is going to live in this
-# process it must be loaded BEFORE libglc_hip.so (which links the system ROCm): the system
-# libamdhip64 then binds to the HSA runtime torch already loaded (same SONAME) and both HIP
-# runtimes share one device context.  The other order creates two HSA runtimes and the second
-# one to initialise sees no device.  Handles (streams, events) never cross between the two HIP
-# runtimes: the context owns its stream and timer; only raw device addresses are exchanged.
+# PyTorch's ROCm wheel bundles its own libamdhip64.so / libhsa-runtime64.so, with the SAME SONAMEs
+# (libamdhip64.so.7, libhsa-runtime64.so.1) as the system ROCm that libglc_hip.so links.  If torch is
+# going to live in this process it must be loaded BEFORE libglc_hip.so: the dynamic loader then
+# satisfies the library's NEEDED entries with the runtime torch already mapped, and the process has
+# ONE HIP runtime - stream and event handles mean the same thing on both sides (glc_ctx_set_stream
+# with a torch stream is sound).  The other order maps two runtimes (torch finds its own by RPATH):
+# the second one to initialise sees no device, and handles must never cross.  hip_runtimes_mapped()
+# reports which world this process is in (tests/test_host.py, tests/test_gpu_parity.py assert one).
 try:  # torch is plumbing (device memory, torch.distributed), not a dependency of the codec
     import torch as _torch  # noqa: F401
 except Exception:  # pragma: no cover - torch absent: the system ROCm runtime alone is fine
@@ -188,6 +190,19 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError if the ABI is incomplete
     _fn.restype = _res
     _fn.argtypes = _args
+
+
+def hip_runtimes_mapped():
+    """Paths of every libamdhip64 mapped into this process (/proc/self/maps).  One entry: torch and
+    libglc_hip.so share a runtime and may exchange hipStream_t handles.  Two: they must not."""
+    import re
+    found = set()
+    with open("/proc/self/maps") as fh:
+        for ln in fh:
+            m = re.search(r"(/\S*libamdhip64[^/\s]*)", ln)
+            if m:
+                found.add(os.path.realpath(m.group(1)))
+    return sorted(found)
 
 
 class GlcError(RuntimeError):

@@ -327,6 +327,15 @@ class _Ctx:
         return T, w, np.float32(n.value), wt, e[:ne.value].copy()
 
     def set_stream(self, raw_stream: int) -> None:
+        """Run this context's kernels on a caller-owned hipStream_t (0 restores the private stream).
+        A handle is only meaningful inside the HIP runtime that created it: refused when the process
+        has mapped two (libglc_hip.so loaded before torch, see _lib.py)."""
+        if raw_stream:
+            from ._lib import hip_runtimes_mapped
+            rts = hip_runtimes_mapped()
+            if len(rts) > 1:
+                raise GlcError(GLC_EINVAL, f"two HIP runtimes are mapped ({rts}): a foreign hipStream_t must not cross; "
+                                           "import torch before glc_amd")
         check(lib.glc_ctx_set_stream(self._h, C.c_void_p(raw_stream)), self._h)
 
     def synchronize(self) -> None:

@@ -163,6 +163,8 @@ struct glc_ctx {
   uint32_t dec_delay = 0;
   uint64_t dec_orig_len = 0, dec_n_pairs = 0, dec_n_raw = 0;
   int d1_variant = 0;    // include/glc_debug.h: which inverse-transform kernel / path to launch
+  hipStream_t probe_stream = nullptr;  // include/glc_debug.h clock probe
+  HostBuf probe_out;
   uint32_t dec_ch = 0;
   uint64_t dec_frames = 0, dec_next = 0;
   bool stream_open = false;  // glc_decode_stream_begin called, last chunk not yet delivered
@@ -342,6 +344,8 @@ void glc_ctx_destroy(glc_ctx *ctx) {
   for (hipEvent_t e : ctx->ev_round)
     if (e) (void)hipEventDestroy(e);
   if (ctx->stream_b) (void)hipStreamDestroy(ctx->stream_b);
+  if (ctx->probe_stream) (void)hipStreamDestroy(ctx->probe_stream);
+  ctx->probe_out.release();
   ctx->coef_b.release();
   if (ctx->down_stream) (void)hipStreamDestroy(ctx->down_stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
@@ -1378,6 +1382,27 @@ int glc_imdct_device(glc_ctx *ctx, const glc_frames *in, uint64_t frame_begin, u
 int glc_debug_set_imdct_variant(glc_ctx *ctx, int variant) {
   if (!ctx || variant < 0 || variant > 4) return fail(ctx, GLC_EINVAL, "glc_debug_set_imdct_variant: variant must be 0..4");
   ctx->d1_variant = variant;
+  return GLC_OK;
+}
+
+int glc_debug_clock_probe_begin(glc_ctx *ctx, uint32_t window_us) {
+  if (!ctx || window_us == 0) return fail(ctx, GLC_EINVAL, "glc_debug_clock_probe_begin: bad argument");
+  DeviceGuard guard(ctx->device);
+  if (!ctx->probe_stream) GLC_HIP(ctx, hipStreamCreateWithFlags(&ctx->probe_stream, hipStreamNonBlocking));
+  GLC_HIP(ctx, ctx->probe_out.reserve(64));  // pinned: the wave writes its two counters straight to the host
+  std::memset(ctx->probe_out.p, 0, 16);
+  GLC_HIP(ctx, glc::launch_clock_probe(static_cast<uint64_t>(window_us) * 100ull, static_cast<uint64_t *>(ctx->probe_out.p),
+                                       ctx->probe_stream));
+  return GLC_OK;
+}
+
+int glc_debug_clock_probe_end(glc_ctx *ctx, float *ghz) {
+  if (!ctx || !ghz || !ctx->probe_stream) return fail(ctx, GLC_EINVAL, "glc_debug_clock_probe_end: no probe running");
+  DeviceGuard guard(ctx->device);
+  GLC_HIP(ctx, hipStreamSynchronize(ctx->probe_stream));
+  const uint64_t *o = static_cast<const uint64_t *>(ctx->probe_out.p);
+  if (o[1] == 0) return fail(ctx, GLC_EHIP, "glc_debug_clock_probe_end: the probe reported nothing");
+  *ghz = static_cast<float>(static_cast<double>(o[0]) / static_cast<double>(o[1]) * 0.1);
   return GLC_OK;
 }
 

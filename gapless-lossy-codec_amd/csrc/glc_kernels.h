@@ -80,4 +80,8 @@ hipError_t launch_overlap_add(const float *blocks, int64_t blk_frame0, uint64_t 
                               uint32_t ch, uint64_t hop_begin, uint64_t hop_end, float *out,
                               hipStream_t s);
 
+// Measurement only (include/glc_debug.h): one sleeping wave that reports {shader cycles, 100 MHz ticks}
+// over a window of `ticks_100mhz` reference ticks, beside whatever runs on the device meanwhile.
+hipError_t launch_clock_probe(uint64_t ticks_100mhz, uint64_t *out, hipStream_t s);
+
 }  // namespace glc

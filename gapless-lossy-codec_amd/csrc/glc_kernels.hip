@@ -935,6 +935,37 @@ __global__ __launch_bounds__(256) void k_pack_rows(const unsigned char *__restri
   for (unsigned pos = done + lane; pos < room; pos += 64) dst[pos] = 0xFFFFu;
 }
 
+// ------------------------------------------------------------------------------------------
+// Clock probe (include/glc_debug.h, measurement only): ONE wave that sleeps beside whatever else runs
+// on the device and reads the shader-clock counter (s_memtime) against the constant 100 MHz counter
+// (s_memrealtime) over `ticks_100mhz`: shader cycles / reference ticks x 100 MHz = the clock the chip
+// held over that window (MI355X_MICROARCH.md, DVFS give-back item 6).  It executes a handful of scalar
+// instructions per microsecond; nothing of the product reads what it writes.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_clock_probe(unsigned long long ticks_100mhz, unsigned long long *__restrict__ out) {
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long r1 = r0;
+  while (r1 - r0 < ticks_100mhz) {
+    __builtin_amdgcn_s_sleep(32);
+    r1 = __builtin_amdgcn_s_memrealtime();
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) {
+    out[0] = t1 - t0;
+    out[1] = r1 - r0;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_clock_probe(uint64_t ticks_100mhz, uint64_t *out, hipStream_t s) {
+  hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, s, static_cast<unsigned long long>(ticks_100mhz),
+                     reinterpret_cast<unsigned long long *>(out));
+  return hipGetLastError();
+}
+
+namespace {
 }  // namespace
 
 // ---------------------------------------------------------------------------- launchers

@@ -24,6 +24,14 @@ extern "C" {
  * All of them produce the same bits; tools/soak_decode.py checks that on random streams. */
 int glc_debug_set_imdct_variant(glc_ctx *ctx, int variant);
 
+/* The shader clock the device HOLDS under load (measurement only; bench.py's roofline.clock_ghz_held).
+ * `begin` starts one sleeping wave on a stream of its own that runs for `window_us` microseconds beside
+ * whatever the caller queues meanwhile and reads the shader-cycle counter against the constant 100 MHz
+ * counter; `end` waits for it and returns cycles / ticks x 0.1 GHz.  The caller keeps the device busy
+ * with the kernel of interest for at least the window. */
+int glc_debug_clock_probe_begin(glc_ctx *ctx, uint32_t window_us);
+int glc_debug_clock_probe_end(glc_ctx *ctx, float *ghz);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1132,3 +1132,20 @@ def test_pipelined_encode_contexts_come_and_go_and_run_side_by_side(torch_cuda):
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+def test_torch_and_library_share_one_hip_runtime(torch_cuda):
+    """is a torch stream handle passed to glc_ctx_set_stream a foreign pointer?  No: with
+    torch imported first (glc_amd/_lib.py does) the loader resolves libglc_hip.so's libamdhip64.so.7 to
+    the runtime torch bundles (same SONAME), so exactly one HIP runtime is mapped after both sides have
+    initialised the device, and an event recorded by torch on its stream orders work the library queues."""
+    from glc_amd._lib import hip_runtimes_mapped
+    torch = torch_cuda
+    enc = glc_amd.Encoder(48000)
+    rts = hip_runtimes_mapped()
+    assert len(rts) == 1, rts
+    assert glc_amd.lib.glc_ctx_device(enc._h) == torch.cuda.current_device()
+    s = torch.cuda.Stream()
+    enc.set_stream(s.cuda_stream)   # refused (GlcError) if a second runtime were mapped
+    assert glc_amd.lib.glc_ctx_stream(enc._h) == s.cuda_stream
+    enc.set_stream(0)

@@ -210,3 +210,19 @@ def test_host_parsers_under_address_and_ub_sanitizers(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe), "6", str(tmp_path), "0x5eed"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "rounds clean" in r.stdout, r.stderr[-3000:]
+
+
+def test_one_hip_runtime_is_mapped():
+    """torch's wheel bundles a libamdhip64 with the system ROCm's SONAME; glc_amd imports torch first, so
+    the loader gives libglc_hip.so the runtime torch mapped: ONE runtime, stream handles may cross
+    (tests/test_gpu_parity.py passes torch streams to glc_ctx_set_stream).  The other import order maps
+    two; shown in a child process."""
+    import subprocess
+    import sys
+    from glc_amd._lib import hip_runtimes_mapped
+    assert len(hip_runtimes_mapped()) == 1, hip_runtimes_mapped()
+    code = ("import ctypes, sys; sys.path.insert(0, %r); ctypes.CDLL(%r); import torch; import re; "
+            "print(len({m.group(1) for l in open('/proc/self/maps') for m in [re.search(r'(/\\S*libamdhip64[^/\\s]*)', l)] if m}))"
+            % (ROOT, glc_amd.LIB_PATH))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "2", out.stdout + out.stderr

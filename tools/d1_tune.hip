@@ -1068,6 +1068,7 @@ int main(int argc, char **argv) {
   CHECK(hipEventCreate(&e1));
   hipStream_t st = 0;  // D1_TUNE_STREAM=1: a non-blocking stream like the library's, instead of the null stream
   if (getenv("D1_TUNE_STREAM")) CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  int n_mismatch = 0;  // any bit-exact arm that disagrees with the reference kernel fails the harness (exit code 1)
   auto run = [&](const char *name, bool exact, auto launch) {
     CHECK(hipMemset(d_out, 0xFF, size_t(M) * 2048 * 4));
     for (int i = 0; i < 5; ++i) launch();
@@ -1087,7 +1088,7 @@ int main(int argc, char **argv) {
     const double tf = double(total) * 2048 * 2 / (ms * 1e-3) / 1e12;
     printf("%-44s %8.1f us  %6.2f TFLOP/s (%.3f of 78.65)  %s\n", name, ms * 1e3, tf, tf / 78.65,
            exact ? (bad ? "MISMATCH" : "bit-exact") : "(ablation: results not meaningful)");
-    if (exact && bad) printf("   %llu words differ\n", bad);
+    if (exact && bad) printf("   %llu words differ\n", bad), ++n_mismatch;
     fflush(stdout);
   };
   const unsigned g8 = ((nf + 7) / 8) * ch, g16 = ((nf + 15) / 16) * ch;
@@ -1138,16 +1139,24 @@ int main(int argc, char **argv) {
     hipLaunchKernelGGL(k_plan, dim3(g8), dim3(256), 0, st, R, nf, ch, d_hdr, d_prec, 4u);
     hipLaunchKernelGGL((k_apply_pair<true, 4, 4>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, (unsigned long long *)nullptr);
   });
+  // every arm that reads the plan re-plans first with the `ahead` ITS apply kernel expects (round 2's
+  // listing ran the two R = 2 arms below on the ahead-4 plan of the arm above: 16 M words differed)
+  auto replan = [&](unsigned ahead) {
+    hipLaunchKernelGGL(k_plan, dim3(g8), dim3(256), 0, st, R, nf, ch, d_hdr, d_prec, ahead);
+    CHECK(hipStreamSynchronize(st));
+  };
+  replan(2u);
   run("C2 apply_pair alone + priority ladder", true, [&] {
     hipLaunchKernelGGL((k_apply_pair<true, 4, 2, 1, false>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, (unsigned long long *)nullptr);
   });
   run("C2 apply_pair alone + priority ladder + per-row skip (shipped)", true, [&] {
     hipLaunchKernelGGL((k_apply_pair<true, 4, 2, 1, true>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, (unsigned long long *)nullptr);
   });
+  replan(4u);
   run("C2 apply_pair R=4 alone", true, [&] {
     hipLaunchKernelGGL((k_apply_pair<true, 4, 4>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out, (unsigned long long *)nullptr);
   });
-  hipLaunchKernelGGL(k_plan, dim3(g8), dim3(256), 0, st, R, nf, ch, d_hdr, d_prec, 2u);  // back to the R = 2 plan
+  replan(2u);  // back to the R = 2 plan
   unsigned *d_order = nullptr;
   {  // balanced placement: blocks b, b + 256, b + 512, b + 768 share a CU (measured: the dispatcher deals an empty
      // chip in that order), so units are sorted by work and dealt in a snake over the 256 CU slots
@@ -1303,11 +1312,15 @@ int main(int argc, char **argv) {
       snprintf(name, sizeof name, "L library plan + apply, debug variant %d", v);
       run(name, true, [&] { CHECK(glc::launch_imdct_rows(tb, LR, 0, M, ch, d_out, st, v, d_lplan, 2048)); });
     }
+    // a repeated decode of one stream: the plan records and the unit order are still in the workspace
+    run("L library apply alone (plan kept by the context: repeat decode), variant 0", true,
+        [&] { CHECK(glc::launch_imdct_rows(tb, LR, 0, M, ch, d_out, st, 0, d_lplan, 2048, /*reuse_plan=*/true)); });
   }
   run("C apply alone (plan from the previous run) skip1", true, [&] {
     hipLaunchKernelGGL((k_apply<true, false, 4>), dim3(gridC), dim3(256), 0, st, dT, dw, norm, d_hdr, d_prec, nf, ch, d_out);
   });
   run("B G16 nt0 w4", true, [&] { hipLaunchKernelGGL((k_chan16<false, 4>), dim3(g16), dim3(512), 0, st, dT, dw, norm, R, nf, ch, d_out); });
   run("B G16 nt1 w4", true, [&] { hipLaunchKernelGGL((k_chan16<true, 4>), dim3(g16), dim3(512), 0, st, dT, dw, norm, R, nf, ch, d_out); });
-  return 0;
+  if (n_mismatch) printf("FAILED: %d bit-exact arm(s) disagree with the reference kernel\n", n_mismatch);
+  return n_mismatch ? 1 : 0;
 }

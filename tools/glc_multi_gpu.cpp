@@ -227,11 +227,45 @@ int main(int argc, char **argv) {
   uint64_t gathered = 0;
   NCCL_OK(ncclGroupStart());
   for (int r = 1; r < world; ++r) {
+    // each call on the device its communicator and stream belong to
+    HIP_OK(hipSetDevice(dev[r].id));
     NCCL_OK(ncclSend(dev[r].d_blob, dev[r].info.bytes, ncclUint8, 0, comm[r], dev[r].stream));
+    HIP_OK(hipSetDevice(dev[0].id));
     NCCL_OK(ncclRecv(d_root + off[r], dev[r].info.bytes, ncclUint8, r, comm[0], dev[0].stream));
     gathered += dev[r].info.bytes;
   }
   NCCL_OK(ncclGroupEnd());
+  // A first multi-rank failure must name its rank: wait for every rank's stream with a deadline
+  // instead of blocking in one hipStreamSynchronize for ever.
+  {
+    const double limit_s = std::getenv("GLC_GATHER_TIMEOUT_S") ? std::atof(std::getenv("GLC_GATHER_TIMEOUT_S")) : 120.0;
+    const auto t_start = std::chrono::steady_clock::now();
+    std::vector<char> done(world, 0);
+    int left = world;
+    while (left > 0) {
+      for (int r = 0; r < world; ++r) {
+        if (done[r]) continue;
+        HIP_OK(hipSetDevice(dev[r].id));
+        const hipError_t q = hipStreamQuery(dev[r].stream);
+        if (q == hipSuccess) {
+          done[r] = 1;
+          --left;
+        } else if (q != hipErrorNotReady) {
+          std::fprintf(stderr, "glc_multi_gpu: rank %d (device %d): %s while gathering %llu bytes\n", r, dev[r].id,
+                       hipGetErrorString(q), static_cast<unsigned long long>(dev[r].info.bytes));
+          return 3;
+        }
+      }
+      if (left > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() > limit_s) {
+        for (int r = 0; r < world; ++r)
+          if (!done[r])
+            std::fprintf(stderr, "glc_multi_gpu: rank %d (device %d) has not finished its %s of %llu bytes after %.0f s\n", r,
+                         dev[r].id, r == 0 ? "receives" : "send", static_cast<unsigned long long>(dev[r].info.bytes), limit_s);
+        return 3;
+      }
+    }
+    HIP_OK(hipSetDevice(dev[0].id));
+  }
   // root: blobs to the host (pinned), assemble
   uint8_t *h_root = nullptr;
   HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&h_root), root_bytes, hipHostMallocDefault));
