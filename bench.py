@@ -84,6 +84,8 @@ def launch_ranks(args):
            "--spinup", str(args.spinup)]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
+    if args.lean:
+        cmd.append("--lean")
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
     line = None
     for ln in p.stdout.decode("utf-8", "replace").splitlines():
@@ -103,6 +105,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lean", action="store_true",
+                    help="only the timed steps and the K1 leg (profiling runs: no other rates, decode, host boundary, CPU baseline, child process)")
     ap.add_argument("--spinup", type=int, default=SPINUP_STEPS,
                     help="untimed steps before --warmup that bring the device clock up after the idle set-up phase")
     args = ap.parse_args()
@@ -255,7 +259,7 @@ def main():
     k1()
     # the clock the chip HOLDS under this kernel: one sleeping wave reads the shader-cycle counter against
     # the 100 MHz reference over ~60 % of the timed launches (include/glc_debug.h; measurement only)
-    probe_ok = L.glc_debug_clock_probe_begin(enc._h, int(0.6 * k1_reps * 550)) == 0
+    probe_ok = (not args.lean) and L.glc_debug_clock_probe_begin(enc._h, int(0.6 * k1_reps * 550)) == 0
     enc.timer_begin()          # HIP events on the stream the kernels are launched on
     for _ in range(k1_reps):
         k1()
@@ -277,7 +281,7 @@ def main():
     # ---- the north_star's 44.1 / 96 kHz variants of the same batch (only the band tables of the
     # quantiser depend on the rate; reported beside the headline, never as `value`) ------------
     other_rates = {}
-    for sr2 in (44100, 96000):
+    for sr2 in (() if args.lean else (44100, 96000)):
         e2 = glc_amd.Encoder(sr2, device=local_rank)
         reps = max(10, min(args.steps, 50))
         for _ in range(args.spinup):  # the device clocked down while the host built this rate's tables
@@ -298,6 +302,7 @@ def main():
                                  "ms_per_step_events": round(max(ms_all), 4),
                                  "ms_per_step_events_min_over_ranks": round(min(ms_all), 4)}
         e2.close()
+    other_rates = other_rates or None
     # restore the 48 kHz records for the checks below
     step()
     enc.synchronize()
@@ -314,7 +319,7 @@ def main():
 
     # ---- sanity: records of this run assemble into a valid stream (rank 0, own shard) ----
     encoded = None
-    if rank == 0:
+    if rank == 0 and not args.lean:
         # (rank 0's 4096 records, indexed as a stream of their own: the bookkeeping below is per GPU)
         ea = glc_amd.EncodedAudio.from_records(SR, FRAMES_PER_GPU * HOP * CH, CH, d_rec.cpu().numpy())
         i = ea.info()
@@ -326,7 +331,7 @@ def main():
     # ---- PCIe-inclusive host boundary (Encoder::encode from host memory + save_encoded bytes);
     # reported beside the headline, never as `value` -------------------------------------------
     host_boundary = None
-    if rank == 0:
+    if rank == 0 and not args.lean:
         best = None
         ea_h = blob = None
         for _ in range(60):  # the device clocked down while the records came back to the host: 75 ms of the same call
@@ -379,7 +384,7 @@ def main():
     # ---- decode of the same batch, device-resident (sparse rows resident -> interleaved PCM in
     # HBM): D1 sparse IMDCT + window, D2 overlap-add.  Beside the headline, never `value`. ---------
     decode = None
-    if rank == 0:
+    if rank == 0 and not args.lean:
         ea_d = glc_amd.EncodedAudio.from_records(SR, FRAMES_PER_GPU * HOP * CH, CH, d_rec.cpu().numpy())
         dec = glc_amd.Decoder(CH, SR, device=local_rank)
         d_all = torch.empty((FRAMES_PER_GPU + 1) * HOP * CH, dtype=torch.float32, device="cuda")
@@ -423,7 +428,7 @@ def main():
 
     # ---- CPU baseline: the oracle (a port of src/codec.rs) on this box's cores, rank 0, N=1
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline and not args.lean:
         from oracle import oracle as O  # checker/baseline only — never on the product path
         cores = min(16, os.cpu_count() or 1)  # a one-GPU box's CPU share is 16 cores (the other ranks idle in the barrier below)
         nfr = FRAMES_PER_GPU  # the full cfg2 batch, timed twice (~15 core-seconds of CPU work)

@@ -1063,11 +1063,13 @@ int decode_prepare_impl(glc_ctx *ctx, const glc_frames *in) {
   int64_t *row_raw = reinterpret_cast<int64_t *>(hb + h_raw);
   uint64_t *row_raw_len = reinterpret_cast<uint64_t *>(hb + h_rawlen);
   for (uint64_t m = 0; m < M; ++m) row_raw[m] = -1;
+  uint32_t any_raw = 0;
   std::vector<uint32_t> extra;  // canonicalised copies of non-canonical lists
   std::vector<int32_t> dense;
   const uint64_t n_stored = in->pairs.size();
   for (uint64_t f = 0; f < nf; ++f) {
     if (in->raw_tag[f]) {
+      any_raw = 1;
       for (uint32_t c = 0; c < ch; ++c) {
         row_raw[f * ch + c] = static_cast<int64_t>(in->raw_begin[f]);
         row_raw_len[f * ch + c] = in->raw_begin[f + 1] - in->raw_begin[f];
@@ -1144,7 +1146,7 @@ int decode_prepare_impl(glc_ctx *ctx, const glc_frames *in) {
                                   reinterpret_cast<const float *>(mb + o_scale),
                                   reinterpret_cast<const int64_t *>(mb + o_raw),
                                   reinterpret_cast<const uint64_t *>(mb + o_rawlen),
-                                  reinterpret_cast<const int16_t *>(mb + o_pool)};
+                                  reinterpret_cast<const int16_t *>(mb + o_pool), any_raw};
   ctx->dec_ch = ch;
   ctx->dec_frames = nf;
   ctx->dec_next = 0;

@@ -62,6 +62,7 @@ struct DecodeRows {
   const int64_t *row_raw;
   const uint64_t *row_raw_len;
   const int16_t *raw_pool;
+  uint32_t any_raw;  // the stream has rows of raw frames (their blocks are written by a kernel of their own)
 };
 // variant (include/glc_debug.h): 0 = shipped (k_imdct_plan + k_imdct_apply, absent row pairs skipped
 // by scalar branches); 1 = one row per workgroup (the cross-check kernel); 2 = plan + apply without

@@ -475,11 +475,34 @@ __global__ __launch_bounds__(256) void k_imdct_plan(DecodeRows rows, unsigned ro
 #pragma unroll
     for (int g = 0; g < G; ++g) total += n[g];
     const unsigned dense = n_u * G <= 2u * total ? 1u : 0u;
-    // h[7]: rows of raw frames (written by the apply kernel: the plan may outlive one launch, the blocks do not)
+    // h[7]: rows of raw frames (written by k_imdct_raw_rows on every launch: the plan may outlive one, the blocks do not)
     h[tid] = tid == 0 ? n_u : tid == 1 ? live : tid < 2 + ahead ? static_cast<unsigned>(s_u[tid - 2]) << 13 : tid == 6 ? dense : tid == 7 ? rawm : 0u;
     // work of the unit for the placement below: packed operations it issues (stored non-zeros) plus
     // the per-entry overhead of walking its union (record fetch, table row)
     if (tid == 0) plan_work[blockIdx.x] = total + n_u + (rawm ? 64u : 0u);
+  }
+}
+
+// Rows of raw frames of a launch (streams that have any): read as if interleaved (Q1), /32767, no window
+// (Q2) - src/codec.rs:629-640.  One workgroup per row; rows of compressed frames return at once.  Its
+// own kernel so that the apply kernel stays free of the division's fused expansion (tools/check_isa.py)
+// and a kept plan (launch_d1) never leaves these blocks unwritten.
+__global__ __launch_bounds__(256) void k_imdct_raw_rows(DecodeRows rows, unsigned row_begin, unsigned M, unsigned ch,
+                                                         float *__restrict__ blocks) {
+  const unsigned r = blockIdx.x;
+  if (r >= M) return;
+  const unsigned m = row_begin + r;
+  const long long raw_off = rows.row_raw[m];
+  if (raw_off < 0) return;
+  const unsigned c = m % ch;
+  const unsigned long long raw_len = rows.row_raw_len[m];
+  const short *raw = rows.raw_pool + raw_off;
+  float *out = blocks + static_cast<size_t>(r) * kFrameI;
+  for (int i = threadIdx.x; i < kFrameI; i += 256) {
+    const unsigned long long si = static_cast<unsigned long long>(i) * ch + c;
+    float v = 0.0f;
+    if (si < raw_len) v = static_cast<float>(raw[si]) / 32767.0f;
+    out[i] = v;
   }
 }
 
@@ -494,17 +517,26 @@ __global__ __launch_bounds__(256) void k_imdct_plan(DecodeRows rows, unsigned ro
 constexpr unsigned kOrderMaxUnits = 4096;
 __global__ __launch_bounds__(256) void k_imdct_order(const unsigned *__restrict__ plan_work, unsigned n_units,
                                                       unsigned *__restrict__ order) {
-  __shared__ unsigned s_key[kOrderMaxUnits];
-  for (unsigned i = threadIdx.x; i < n_units; i += 256) s_key[i] = plan_work[i];
+  __shared__ __attribute__((aligned(16))) unsigned s_key[kOrderMaxUnits];
+  const unsigned n4 = (n_units + 3u) & ~3u;
+  for (unsigned i = threadIdx.x; i < n4; i += 256) s_key[i] = i < n_units ? plan_work[i] : 0u;  // padding keys rank below every unit
   __syncthreads();
   const unsigned u = blockIdx.x * 256 + threadIdx.x;
   if (u >= n_units) return;
   const unsigned mine = s_key[u];
-  unsigned rank = 0;
-  for (unsigned j = 0; j < n_units; ++j) {
-    const unsigned k = s_key[j];
-    rank += (k > mine || (k == mine && j < u)) ? 1u : 0u;
+  // rank = units with more work, or equal work and a lower index: key (work, ~index) as one 64-bit compare
+  // would do; two counters keep it in 32-bit ops.  Four keys per LDS read (every lane reads the same
+  // address: a broadcast), eight reads in flight.
+  unsigned above = 0, ties_before = 0;
+  const uint4 *k4 = reinterpret_cast<const uint4 *>(s_key);
+#pragma unroll 8
+  for (unsigned j = 0; j < n4 / 4; ++j) {
+    const uint4 k = k4[j];
+    above += (k.x > mine) + (k.y > mine) + (k.z > mine) + (k.w > mine);
+    const unsigned b = j * 4;
+    ties_before += (k.x == mine && b < u) + (k.y == mine && b + 1 < u) + (k.z == mine && b + 2 < u) + (k.w == mine && b + 3 < u);
   }
+  const unsigned rank = above + ties_before;
   unsigned pos = rank;
   if (rank < 1024u) {
     const unsigned round = rank >> 8, p = rank & 255u;
@@ -578,9 +610,9 @@ __device__ __forceinline__ void d1_mac2rows_fine_s(d1x2 (&c0)[4], d1x2 (&c1)[4],
 // measured and bought nothing: tools/d1_tune.hip, profiles/r02_d1_*).
 template <bool SKIP, bool PRIO = true, bool FINE = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void k_imdct_apply(DeviceTables tb, DecodeRows rows, unsigned row_begin, const unsigned *__restrict__ plan_hdr,
-                   const unsigned *__restrict__ plan_rec, const unsigned *__restrict__ order, unsigned n_frames, unsigned ch,
-                   unsigned group_begin, unsigned n_units, float *__restrict__ blocks) {
+void k_imdct_apply(DeviceTables tb, const unsigned *__restrict__ plan_hdr, const unsigned *__restrict__ plan_rec,
+                   const unsigned *__restrict__ order, unsigned n_frames, unsigned ch, unsigned group_begin, unsigned n_units,
+                   float *__restrict__ blocks) {
   constexpr int G = 8, R = 2;
   // block -> unit (frame group, channel) of this batch.  (Speed only.)  All units of a launch of
   // <= 1024 are resident at once, four to a CU, and the dispatcher deals an empty chip so that blocks
@@ -606,25 +638,6 @@ void k_imdct_apply(DeviceTables tb, DecodeRows rows, unsigned row_begin, const u
   const unsigned *hdr = plan_hdr + static_cast<size_t>(local) * kPlanHdrDwords;
   const unsigned n_u = __builtin_amdgcn_readfirstlane(hdr[0]);
   const unsigned live = __builtin_amdgcn_readfirstlane(hdr[1]);
-  const unsigned rawm = __builtin_amdgcn_readfirstlane(hdr[7]);
-  if (rawm) {  // raw frames: read as if interleaved (Q1), /32767, no window (Q2) - src/codec.rs:629-640
-#pragma unroll 1
-    for (int g = 0; g < G; ++g) {
-      if (!(rawm & (1u << g))) continue;
-      const unsigned r = (fr0 + g) * ch + c;
-      const unsigned m = row_begin + r;
-      float *out = blocks + static_cast<size_t>(r) * kFrameI;
-      const unsigned long long raw_len = rows.row_raw_len[m];
-      const short *raw = rows.raw_pool + rows.row_raw[m];
-#pragma unroll 1
-      for (int i = threadIdx.x; i < kFrameI; i += 256) {
-        const unsigned long long si = static_cast<unsigned long long>(i) * ch + c;
-        float v = 0.0f;
-        if (si < raw_len) v = static_cast<float>(raw[si]) / 32767.0f;
-        out[i] = v;
-      }
-    }
-  }
   if (!live) return;
   // The four waves of a SIMD are arbitrated oldest-first, so left alone they finish one after the
   // other and the last one runs by itself, with nobody to fill its scalar and wait slots.  Each wave
@@ -1069,6 +1082,7 @@ hipError_t launch_imdct_rows(const DeviceTables &t, const DecodeRows &rows, uint
   unsigned *order = work + plan_groups;
   const uint32_t fg_per_batch = plan_groups / ch;
   if (reuse_plan && groups > fg_per_batch) return hipErrorInvalidValue;  // only a one-batch launch leaves its plan behind
+  if (rows.any_raw) hipLaunchKernelGGL(k_imdct_raw_rows, dim3(M), dim3(256), 0, s, rows, row_begin, M, ch, blocks);
   for (uint32_t fg0 = 0; fg0 < groups; fg0 += fg_per_batch) {
     const uint32_t n_fg = groups - fg0 < fg_per_batch ? groups - fg0 : fg_per_batch;
     const uint32_t n_units = n_fg * ch;
@@ -1081,13 +1095,13 @@ hipError_t launch_imdct_rows(const DeviceTables &t, const DecodeRows &rows, uint
     }
     const unsigned *ord = ranked ? order : nullptr;
     if (variant == 2)
-      hipLaunchKernelGGL(k_imdct_apply<false>, grid, dim3(256), 0, s, t, rows, row_begin, hdr, rec, ord, n_frames, ch, fg0, n_units, blocks);
+      hipLaunchKernelGGL(k_imdct_apply<false>, grid, dim3(256), 0, s, t, hdr, rec, ord, n_frames, ch, fg0, n_units, blocks);
     else if (variant == 4)
-      hipLaunchKernelGGL((k_imdct_apply<true, true, false>), grid, dim3(256), 0, s, t, rows, row_begin, hdr, rec, ord, n_frames, ch, fg0, n_units, blocks);
+      hipLaunchKernelGGL((k_imdct_apply<true, true, false>), grid, dim3(256), 0, s, t, hdr, rec, ord, n_frames, ch, fg0, n_units, blocks);
     else if (variant == 3)
-      hipLaunchKernelGGL((k_imdct_apply<true, false>), grid, dim3(256), 0, s, t, rows, row_begin, hdr, rec, ord, n_frames, ch, fg0, n_units, blocks);
+      hipLaunchKernelGGL((k_imdct_apply<true, false>), grid, dim3(256), 0, s, t, hdr, rec, ord, n_frames, ch, fg0, n_units, blocks);
     else
-      hipLaunchKernelGGL(k_imdct_apply<true>, grid, dim3(256), 0, s, t, rows, row_begin, hdr, rec, ord, n_frames, ch, fg0, n_units, blocks);
+      hipLaunchKernelGGL(k_imdct_apply<true>, grid, dim3(256), 0, s, t, hdr, rec, ord, n_frames, ch, fg0, n_units, blocks);
   }
   return hipGetLastError();
 }

@@ -1306,7 +1306,7 @@ int main(int argc, char **argv) {
     tb.window = dw;
     tb.norm = norm;
     glc::DecodeRows LR{d_pairs, reinterpret_cast<const uint64_t *>(d_begin), d_cnt, d_scale, reinterpret_cast<const int64_t *>(d_rowraw),
-                       reinterpret_cast<const uint64_t *>(d_rawlen), nullptr};
+                       reinterpret_cast<const uint64_t *>(d_rawlen), nullptr, 0u};
     for (int v : {0, 4, 3, 2, 0}) {
       char name[96];
       snprintf(name, sizeof name, "L library plan + apply, debug variant %d", v);

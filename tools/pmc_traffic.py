@@ -61,7 +61,7 @@ def main():
     args = ap.parse_args()
     scratch = os.path.join(ROOT, "gpurun_out", f"{args.tag}_pmc")
     calib = [os.path.join(ROOT, "build", "fetch_calib")]
-    bench = ["python3", os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-cpu-baseline"]
+    bench = ["python3", os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--lean"]
     true_kb = 512 * 1024.0
 
     cf = run_pass(["FETCH_SIZE"], calib, os.path.join(scratch, "calib_fetch"))
@@ -83,7 +83,7 @@ def main():
     bw = run_pass(["WRITE_SIZE"], bench, os.path.join(scratch, "bench_write"))
     bh = run_pass(["TCC_HIT_sum", "TCC_MISS_sum"], bench, os.path.join(scratch, "bench_tcc"))
     kernels = {}
-    for label, needle in (("K1", K1), ("K2", "k_quantize"), ("D1", "k_imdct_apply"), ("D2", "k_overlap_add")):
+    for label, needle in (("K1", K1), ("K2", "k_quantize")):
         f, n = pick(bf, needle, "FETCH_SIZE")
         w, _ = pick(bw, needle, "WRITE_SIZE")
         h, _ = pick(bh, needle, "TCC_HIT_sum")
