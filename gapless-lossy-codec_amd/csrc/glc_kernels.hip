@@ -983,6 +983,8 @@ namespace {
 
 // ---------------------------------------------------------------------------- launchers
 
+constexpr int kK1Prio = 1;  // glc_mdct_fwd.hpp PRIO: priority by quarter of the i loop (k1_tune: 0.560 against 0.572-0.605 ms at config 2)
+
 hipError_t launch_mdct_forward(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin,
                                uint32_t M, float *coef, hipStream_t s) {
   // Shapes measured with tools/k1_tune.hip (profiles/r01_k1_tune_*.txt).  The f32 VALU needs
@@ -999,11 +1001,11 @@ hipError_t launch_mdct_forward(const DeviceTables &t, const PcmView &pcm, uint64
   // 512 threads, 4x8 per lane, table tile by LDS-DMA; PCM by one dwordx4 per lane and stage when the
   // channel count divides the tile height, else one dword per (row, sample)
   switch (pcm.ch) {
-    case 1: return k1::launch_dma<4, 1>(t, pcm, frame_begin, M, coef, s);
-    case 2: return k1::launch_dma<4, 2>(t, pcm, frame_begin, M, coef, s);
-    case 4: return k1::launch_dma<4, 4>(t, pcm, frame_begin, M, coef, s);
-    case 8: return k1::launch_dma<4, 8>(t, pcm, frame_begin, M, coef, s);
-    default: return k1::launch_dma<4>(t, pcm, frame_begin, M, coef, s);
+    case 1: return k1::launch_dma<4, 1, kK1Prio>(t, pcm, frame_begin, M, coef, s);
+    case 2: return k1::launch_dma<4, 2, kK1Prio>(t, pcm, frame_begin, M, coef, s);
+    case 4: return k1::launch_dma<4, 4, kK1Prio>(t, pcm, frame_begin, M, coef, s);
+    case 8: return k1::launch_dma<4, 8, kK1Prio>(t, pcm, frame_begin, M, coef, s);
+    default: return k1::launch_dma<4, 0, kK1Prio>(t, pcm, frame_begin, M, coef, s);
   }
 }
 

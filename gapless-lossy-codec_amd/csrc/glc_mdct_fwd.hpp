@@ -521,9 +521,17 @@ inline hipError_t launch_sched(const DeviceTables &t, const PcmView &pcm, uint64
 // `s_waitcnt vmcnt(0)` per stage, in the middle of the stage, retires loads that are a stage old.
 // Same arithmetic, same order.
 // ------------------------------------------------------------------------------------------
-template <int MINW, int CH = 0>
+// PRIO (speed only; which one ships is decided by tools/k1_tune.hip): issue priority as a schedule.  The
+// two workgroups of a CU (2 + 2 waves on every SIMD) are arbitrated oldest-first, so left alone the
+// older one takes every issue slot it can use and the younger one fills its gaps - and finishes the
+// kernel alone, two waves to a SIMD.  A wave lowers its own priority as it gets through the i loop, so
+// whichever workgroup is behind goes first:  1 = by quarter of the loop (3, 2, 1, 0);  2 / 3 / 4 = a
+// cycle of four levels every 8 / 16 / 32 stages (the skew stays within a cycle).
+// STAMP (tuning only): workgroup timeline into `stamps` - start, the four quarter points, end.
+template <int MINW, int CH = 0, int PRIO = 0, bool STAMP = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
-void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigned M, float *__restrict__ coef) {
+void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigned M, float *__restrict__ coef,
+                    unsigned long long *__restrict__ stamps) {
   // CH = 0: one PCM dword per (row, i) and lane - any channel count.  CH = 1 / 2 / 4 / 8 (the
   // stream's channel count, which then divides the tile height): a stage's 16 samples x CH channels
   // of one frame are 64 * CH contiguous bytes, fetched by 4 * CH lanes with one dwordx4 each - 16x
@@ -672,8 +680,25 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
   Operands X, Y;
   lds_fetch4<BM, BN>(X, a_lds0, b_lds0, 0);
   lds_wait4(X);
+  if constexpr (STAMP) {
+    if (tid == 0) stamps[static_cast<size_t>(blockIdx.x) * 8] = __builtin_amdgcn_s_memrealtime();
+  }
+  if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(3);
 #pragma unroll 1
   for (int s = 0; s < kStages; ++s) {
+    if constexpr (PRIO != 0) {
+      constexpr int kShift = PRIO == 1 ? 5 : PRIO == 2 ? 1 : PRIO == 3 ? 2 : 3;  // stages per level = 1 << kShift
+      if ((s & ((1 << kShift) - 1)) == 0) {
+        const int level = (s >> kShift) & 3;
+        if (level == 0) __builtin_amdgcn_s_setprio(3);
+        else if (level == 1) __builtin_amdgcn_s_setprio(2);
+        else if (level == 2) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+      }
+    }
+    if constexpr (STAMP) {
+      if (tid == 0 && (s & 31) == 0 && s) stamps[static_cast<size_t>(blockIdx.x) * 8 + (s >> 5)] = __builtin_amdgcn_s_memrealtime();
+    }
     const int slot = s % 3, nslot = (s + 1) % 3;
     const unsigned a_addr = a_lds0 + slot * (BK * BM * 4);
     const unsigned b_addr = b_lds0 + slot * (BK * BN * 4);
@@ -699,6 +724,9 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the wrap-around prefetches
+  if constexpr (STAMP) {
+    if (tid == 0) stamps[static_cast<size_t>(blockIdx.x) * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+  }
 
 #pragma unroll
   for (int r = 0; r < TM; ++r) {
@@ -715,14 +743,15 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
   }
 }
 
-template <int MINW, int CH = 0>
+template <int MINW, int CH = 0, int PRIO = 0, bool STAMP = false>
 inline hipError_t launch_dma(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M,
-                             float *coef, hipStream_t s) {
+                             float *coef, hipStream_t s, unsigned long long *stamps = nullptr) {
   if (M == 0) return hipSuccess;
   if (CH != 0 && pcm.ch != static_cast<uint32_t>(CH)) return hipErrorInvalidValue;
+  if (STAMP && !stamps) return hipErrorInvalidValue;
   const unsigned m_tiles = (M + 127) / 128;
-  hipLaunchKernelGGL((k_mdct_fwd_dma<MINW, CH>), dim3(m_tiles * 8), dim3(512), 0, s, t, pcm,
-                     static_cast<long long>(frame_begin), M, coef);
+  hipLaunchKernelGGL((k_mdct_fwd_dma<MINW, CH, PRIO, STAMP>), dim3(m_tiles * 8), dim3(512), 0, s, t, pcm,
+                     static_cast<long long>(frame_begin), M, coef, stamps);
   return hipGetLastError();
 }
 

@@ -5,6 +5,7 @@
 //        tools/k1_tune.hip -o build/k1_tune
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -49,6 +50,16 @@ __global__ void k_naive(DeviceTables tb, PcmView pcm, long long frame_begin, uns
     s = __fadd_rn(s, __fmul_rn(b, tb.cos_t[(size_t)i * 1024 + k]));
   }
   coef[(size_t)m * 1024 + k] = __fmul_rn(s, tb.norm);
+}
+
+// launch_dma has a defaulted trailing argument (the timeline buffer): adapt it to the harness' signature
+template <int MINW, int CH, int PRIO>
+static hipError_t dma_prio(const DeviceTables &t, const PcmView &pcm, uint64_t f0, uint32_t M, float *coef, hipStream_t s) {
+  return k1::launch_dma<MINW, CH, PRIO>(t, pcm, f0, M, coef, s);
+}
+template <int MINW, int CH = 0>
+static hipError_t dma_shipped(const DeviceTables &t, const PcmView &pcm, uint64_t f0, uint32_t M, float *coef, hipStream_t s) {
+  return k1::launch_dma<MINW, CH>(t, pcm, f0, M, coef, s);
 }
 
 struct Variant {
@@ -134,6 +145,43 @@ int main(int argc, char **argv) {
     return total_bad ? 1 : 0;
   }
 
+  if (fill == "timeline" || (argc > 5 && std::string(argv[5]) == "timeline")) {
+    // workgroup timeline of the dma kernel (stereo): when do the two workgroups of a CU (blocks b, b + 256)
+    // pass the quarter points of the i loop, with and without the priority schedule?
+    if (ch != 2 || M < 4096) return printf("timeline: needs stereo and >= 4096 rows\n"), 1;
+    const unsigned nblk = (M + 127) / 128 * 8;
+    unsigned long long *d_st;
+    CHECK(hipMalloc(&d_st, size_t(nblk) * 64));
+    std::vector<unsigned long long> st(size_t(nblk) * 8);
+    auto show = [&](const char *name, auto launch) {
+      for (int i = 0; i < 20; ++i) CHECK(launch());  // warm clocks
+      CHECK(hipMemset(d_st, 0, size_t(nblk) * 64));
+      CHECK(launch());
+      CHECK(hipDeviceSynchronize());
+      CHECK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+      unsigned long long t0 = ~0ull;
+      for (unsigned b = 0; b < nblk; ++b) t0 = std::min(t0, st[size_t(b) * 8]);
+      printf("%s\n", name);
+      for (int q = 0; q <= 4; ++q) {  // 0 = loop start, 1..3 = quarter points, 4 = loop end
+        std::vector<double> a, d;
+        for (unsigned b = 0; b < nblk; ++b) a.push_back((st[size_t(b) * 8 + q] - t0) * 0.01);
+        for (unsigned b = 0; b + 256 < nblk; ++b) d.push_back(std::fabs(a[b] - a[b + 256]));
+        std::vector<double> sa = a;
+        std::sort(sa.begin(), sa.end());
+        std::sort(d.begin(), d.end());
+        printf("  %-13s us: min %7.1f p10 %7.1f p50 %7.1f p90 %7.1f max %7.1f | partners (b, b + 256) apart: p50 %6.1f p90 %6.1f max %6.1f\n",
+               q == 0 ? "loop start" : q == 4 ? "loop end" : q == 1 ? "1/4 of loop" : q == 2 ? "1/2 of loop" : "3/4 of loop",
+               sa.front(), sa[sa.size() / 10], sa[sa.size() / 2], sa[sa.size() * 9 / 10], sa.back(),
+               d.empty() ? 0.0 : d[d.size() / 2], d.empty() ? 0.0 : d[d.size() * 9 / 10], d.empty() ? 0.0 : d.back());
+      }
+      fflush(stdout);
+    };
+    show("PRIO 0 (shipped)", [&] { return k1::launch_dma<4, 2, 0, true>(tb, pcm, 0, M, d_out, 0, d_st); });
+    show("PRIO 1 (by quarter)", [&] { return k1::launch_dma<4, 2, 1, true>(tb, pcm, 0, M, d_out, 0, d_st); });
+    show("PRIO 3 (cycle of 16 stages)", [&] { return k1::launch_dma<4, 2, 3, true>(tb, pcm, 0, M, d_out, 0, d_st); });
+    return 0;
+  }
+
   hipLaunchKernelGGL(k_naive, dim3(4, M), dim3(256), 0, 0, tb, pcm, 0ll, M, d_ref);
   CHECK(hipDeviceSynchronize());
   std::vector<uint32_t> ref((size_t)M * 1024), out((size_t)M * 1024);
@@ -142,21 +190,29 @@ int main(int argc, char **argv) {
   // hand-scheduled kernels (shipped shapes first), their ablations, then hipcc-scheduled shapes
   std::vector<Variant> vs = {
       // (the first line of a run is measured on a cold device: it is repeated further down)
-      Variant{"warm-up: SHIPPED dma, segment loader", k1::launch_dma<4, 2>},
+      Variant{"warm-up: SHIPPED dma, segment loader", dma_shipped<4, 2>},
       // the three kernels libglc_hip.so ships (csrc/glc_mdct_fwd.hpp)
-      Variant{"SHIPPED dma 128x128 512thr, per-row PCM loader (>= 4096 rows, other channel counts)", k1::launch_dma<4>},
-      Variant{"SHIPPED dma 128x128 512thr, dwordx4 segment loader (>= 4096 rows, stereo)", k1::launch_dma<4, 2>},
+      Variant{"SHIPPED dma 128x128 512thr, per-row PCM loader (>= 4096 rows, other channel counts)", dma_shipped<4>},
+      Variant{"SHIPPED dma 128x128 512thr, dwordx4 segment loader (>= 4096 rows, stereo)", dma_shipped<4, 2>},
       Variant{"SHIPPED sched 64x128 256thr (513..4095 rows)", k1::launch_sched<64, 128, 16, 4>},
       Variant{"SHIPPED hipcc-scheduled 32x64 t4x4 (<= 512 rows)", k1::launch<32, 64, 32, 4, 4, 4, 2>},
+      // issue priority as a schedule (glc_mdct_fwd.hpp PRIO): whichever workgroup of a CU is behind goes first
+      Variant{"dma segment loader, PRIO 1: priority by quarter of the loop (3, 2, 1, 0)", dma_prio<4, 2, 1>},
+      Variant{"dma segment loader, PRIO 2: four levels cycling every 8 stages", dma_prio<4, 2, 2>},
+      Variant{"dma segment loader, PRIO 3: four levels cycling every 16 stages", dma_prio<4, 2, 3>},
+      Variant{"dma segment loader, PRIO 4: four levels cycling every 32 stages", dma_prio<4, 2, 4>},
+      Variant{"SHIPPED dma, segment loader (PRIO 0, again)", dma_shipped<4, 2>},
+      Variant{"dma segment loader, PRIO 1 (again)", dma_prio<4, 2, 1>},
+      Variant{"dma segment loader, PRIO 3 (again)", dma_prio<4, 2, 3>},
       // tuning variants (tools/k1_variants.hpp)
       Variant{"dma segment loader, round-1 protocol: end-of-stage hand-off, counted vmcnt(1)", k1x::launch_dma<4, 0, 128, 2, 0>},
       Variant{"dma segment loader, issue priority alternates between a CU's two workgroups every stage", k1x::launch_dma<4, 0, 128, 2, -1>},
       Variant{"dma segment loader, ... every 2 stages", k1x::launch_dma<4, 0, 128, 2, -2>},
       Variant{"dma segment loader, ... every 8 stages", k1x::launch_dma<4, 0, 128, 2, -8>},
       Variant{"dma segment loader, no stagger (again)", k1x::launch_dma<4, 0, 128, 2, 0>},
-      Variant{"SHIPPED dma, segment loader (again: mid-stage hand-off)", k1::launch_dma<4, 2>},
+      Variant{"SHIPPED dma, segment loader (again: mid-stage hand-off)", dma_shipped<4, 2>},
       Variant{"dma segment loader, end-of-stage hand-off (k1x, again)", k1x::launch_dma<4, 0, 128, 2, 0>},
-      Variant{"SHIPPED dma, segment loader (third time)", k1::launch_dma<4, 2>},
+      Variant{"SHIPPED dma, segment loader (third time)", dma_shipped<4, 2>},
       Variant{"dma segment loader, end-of-stage hand-off (k1x, third time)", k1x::launch_dma<4, 0, 128, 2, 0>},
       Variant{"dma segment loader, odd workgroups start 16 x 64 cycles late", k1x::launch_dma<4, 0, 128, 2, 16>},
       Variant{"dma segment loader, odd workgroups start 32 x 64 cycles late", k1x::launch_dma<4, 0, 128, 2, 32>},
