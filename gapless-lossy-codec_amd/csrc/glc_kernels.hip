@@ -993,10 +993,11 @@ hipError_t launch_mdct_forward(const DeviceTables &t, const PcmView &pcm, uint64
   // workgroups: 2 workgroups = 16 waves per CU at BASELINE config 2, table tile by LDS-DMA.
   // The 8x8-per-lane register-staged kernel measures the same at M >= 16384 (k1_tune), so one
   // kernel serves every batch of 4096 rows or more; short clips use 64-row tiles.
-  // A clip of a few seconds is latency-bound by the 2048-step accumulation chain of one workgroup,
-  // not by throughput: 32x64 tiles with 4x4 outputs per lane halve the work per step and spread
-  // the rows over 16x more workgroups (0.13 ms against 0.19 ms at 172 rows, k1_tune 86 2).
-  if (M <= 512) return k1::launch<32, 64, 32, 4, 4, 4, 2>(t, pcm, frame_begin, M, coef, s);
+  // A clip of a few seconds is latency-bound by one wave's chain of 2048 dependent i-steps, not by
+  // throughput, and the length of a step is the lane tile: cut it until every SIMD has a wave of its own
+  // (2 x 2 outputs per lane up to 256 rows, 2 x 4 up to 512; glc_mdct_fwd.hpp k_mdct_fwd_small).
+  if (M <= 256) return k1::launch_small<2>(t, pcm, frame_begin, M, coef, s);
+  if (M <= 512) return k1::launch_small<4>(t, pcm, frame_begin, M, coef, s);
   if (M < 4096) return k1::launch_sched<64, 128, 16, 4>(t, pcm, frame_begin, M, coef, s);  // short clips: more workgroups
   // 512 threads, 4x8 per lane, table tile by LDS-DMA; PCM by one dwordx4 per lane and stage when the
   // channel count divides the tile height, else one dword per (row, sample)

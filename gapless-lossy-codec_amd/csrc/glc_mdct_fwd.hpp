@@ -755,6 +755,228 @@ inline hipError_t launch_dma(const DeviceTables &t, const PcmView &pcm, uint64_t
   return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Short clips (<= 512 rows: BASELINE config 1 and every clip of the reference's own tests).  A launch
+// this small cannot fill the chip; what it costs is ONE wave's chain of 2048 dependent i-steps, and the
+// length of a step is the lane tile: 128 VALU cycles for 4 x 8 outputs, 16 for 2 x 2.  So the tile is
+// cut until every SIMD of the chip has a wave of its own - 2 x 2 outputs per lane up to 256 rows, 2 x 4
+// up to 512 (65 536 lanes either way) - in 256-thread workgroups (one wave per SIMD of a CU) on
+// 32 x 32 / 32 x 64 tiles.  Same arithmetic, same order; hand-scheduled like the large kernels:
+// operands come from LDS through a four-deep register ring with counted lgkmcnt waits (LDS returns in
+// order), the next stage's global loads are in flight during the stage and only waited for at its end.
+// (Round 2 left this range to hipcc on a 4 x 4 lane tile: 129 VGPRs + 80 B of scratch, 0.13 ms at 172 rows.)
+// ------------------------------------------------------------------------------------------
+#ifndef GLC_SMALL_BK
+#define GLC_SMALL_BK 32  // i-steps per LDS stage of k_mdct_fwd_small (64 measured 4 % slower: gpurun r3d2)
+#endif
+template <int TN>
+struct SmallOps {  // operands of one i-step: a = 2 rows, b = TN columns
+  f32x2 a;
+  f32x2 b[TN / 2];
+};
+
+template <int TN, int BM, int BN>
+__device__ __forceinline__ void small_fetch(SmallOps<TN> &o, unsigned a_addr, unsigned b_addr, int ii) {
+  if constexpr (TN == 2) {
+    asm volatile(
+        "ds_read_b64 %0, %2 offset:%c4\n\t"
+        "ds_read_b64 %1, %3 offset:%c5"
+        : "=&v"(o.a), "=&v"(o.b[0])
+        : "v"(a_addr), "v"(b_addr), "i"(ii * BM * 4), "i"(ii * BN * 4)
+        : "memory");
+  } else {
+    asm volatile(
+        "ds_read_b64 %0, %3 offset:%c5\n\t"
+        "ds_read_b64 %1, %4 offset:%c6\n\t"
+        "ds_read_b64 %2, %4 offset:%c7"
+        : "=&v"(o.a), "=&v"(o.b[0]), "=&v"(o.b[1])
+        : "v"(a_addr), "v"(b_addr), "i"(ii * BM * 4), "i"(ii * BN * 4), "i"(ii * BN * 4 + 8)
+        : "memory");
+  }
+}
+
+// wait until at most PENDING of this wave's LDS reads are outstanding, i.e. `o` (older than those) has landed
+template <int TN, int PENDING>
+__device__ __forceinline__ void small_wait(SmallOps<TN> &o) {
+  if constexpr (TN == 2)
+    asm volatile("s_waitcnt lgkmcnt(%c2)" : "+v"(o.a), "+v"(o.b[0]) : "i"(PENDING) : "memory");
+  else
+    asm volatile("s_waitcnt lgkmcnt(%c3)" : "+v"(o.a), "+v"(o.b[0]), "+v"(o.b[1]) : "i"(PENDING) : "memory");
+}
+
+// c[r][j] += a_r * b_j: rows (a.x, a.y) x TN columns, multiply and add separately rounded
+template <int TN>
+__device__ __forceinline__ void small_mac(f32x2 (&acc)[2][TN / 2], const SmallOps<TN> &o) {
+  if constexpr (TN == 2) {
+    f32x2 t0, t1;
+    asm volatile(
+        "v_pk_mul_f32 %2, %4, %5 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %3, %4, %5 op_sel:[1,0]\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\t"
+        "v_pk_add_f32 %1, %1, %3"
+        : "+v"(acc[0][0]), "+v"(acc[1][0]), "=&v"(t0), "=&v"(t1)
+        : "v"(o.a), "v"(o.b[0]));
+  } else {
+    f32x2 t0, t1, t2, t3;
+    asm volatile(
+        "v_pk_mul_f32 %4, %8, %9 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %5, %8, %10 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %6, %8, %9 op_sel:[1,0]\n\t"
+        "v_pk_mul_f32 %7, %8, %10 op_sel:[1,0]\n\t"
+        "v_pk_add_f32 %0, %0, %4\n\t"
+        "v_pk_add_f32 %1, %1, %5\n\t"
+        "v_pk_add_f32 %2, %2, %6\n\t"
+        "v_pk_add_f32 %3, %3, %7"
+        : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(o.a), "v"(o.b[0]), "v"(o.b[1]));
+  }
+}
+
+// i-steps II .. BK-1 of a stage, written out at compile time: wait for the oldest step of the ring
+// (LDS returns in order: all but the younger steps' reads must have landed), use it, refill its slot
+template <int TN, int BM, int BN, int BK, int D, int II>
+__device__ __forceinline__ void small_steps(f32x2 (&acc)[2][TN / 2], SmallOps<TN> (&ring)[D], unsigned a_addr, unsigned b_addr) {
+  if constexpr (II < BK) {
+    constexpr int R = 1 + TN / 2;
+    constexpr int younger = II + D <= BK ? D - 1 : BK - 1 - II;
+    static_assert(younger * R <= 15, "lgkmcnt is a 4-bit counter");
+    small_wait<TN, younger * R>(ring[II % D]);
+    small_mac<TN>(acc, ring[II % D]);
+    if constexpr (II + D < BK) small_fetch<TN, BM, BN>(ring[II % D], a_addr, b_addr, II + D);
+    small_steps<TN, BM, BN, BK, D, II + 1>(acc, ring, a_addr, b_addr);
+  }
+}
+
+template <int TN>
+__global__ __launch_bounds__(256) void k_mdct_fwd_small(DeviceTables tb, PcmView pcm, long long frame_begin, unsigned M,
+                                                         float *__restrict__ coef) {
+  // D: i-steps of operands in flight (an LDS read takes ~250 cycles under no load, a 2 x 2 step 16 of VALU:
+  // the ring is as deep as the 4-bit lgkmcnt allows - 7 x 2 or 5 x 3 younger reads)
+  constexpr int BM = 32, BN = 16 * TN, BK = GLC_SMALL_BK, D = TN == 2 ? 8 : 6;
+  constexpr int kNTiles = kHopI / BN;
+  constexpr int kAStride = 8, kAPer = BK / kAStride;     // 256 threads = 32 rows x 8 i; i = a_i + 8 j
+  constexpr int kBRowsPer = 256 / (BN / 4), kBPer = BK / kBRowsPer;
+  static_assert(TN == 2 || TN == 4, "lane tile");
+  __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+
+  const int tid = threadIdx.x;
+  const int n_tile = blockIdx.x % kNTiles, m_tile = blockIdx.x / kNTiles;
+  const int m0 = m_tile * BM, n0 = n_tile * BN;
+  const int tx = tid % 16, ty = tid / 16;
+
+  // A operand through a buffer descriptor whose range check is the encoder's zero padding (see k_mdct_fwd)
+  const long long ch = pcm.ch;
+  const long long f0 = frame_begin + m0 / pcm.ch;
+  const long long e_first = (f0 * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * ch;
+  long long e_end = static_cast<long long>(pcm.t_count) * ch;
+  const long long n_rel = static_cast<long long>(pcm.n_samples) - static_cast<long long>(pcm.t0) * ch;
+  if (e_end > n_rel) e_end = n_rel;
+  const long long e_base = e_first < 0 ? 0 : e_first;
+  long long e_cnt = e_end - e_base;
+  if (e_cnt < 0) e_cnt = 0;
+  if (e_cnt > (1ll << 28)) e_cnt = 1ll << 28;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(pcm.p + e_base), 0, static_cast<int>(e_cnt * 4), 0x00020000);
+  const int a_r = tid % BM, a_i = tid / BM;
+  const unsigned a_row = m0 + a_r;
+  unsigned a_off = 0x80000000u;  // out-of-range row: every load returns 0
+  if (a_row < M) {
+    const long long f = frame_begin + a_row / pcm.ch;
+    const long long c = a_row % pcm.ch;
+    const long long e_row = (f * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * ch + c;
+    a_off = static_cast<unsigned>((e_row - e_base + a_i * ch) * 4);  // may wrap: that IS the padding
+  }
+  const unsigned a_step = static_cast<unsigned>(kAStride * ch * 4);
+  const float *w_ptr = tb.window + a_i;
+  const int b_r = tid / (BN / 4), b_c4 = tid % (BN / 4);
+  const float *b_ptr = tb.cos_t + n0 + static_cast<size_t>(b_r) * kHopI + b_c4 * 4;
+
+  float a_raw[kAPer], a_win[kAPer];
+  f32x4 b_stage[kBPer];
+  auto load_stage = [&](int i0) {
+    const unsigned off0 = a_off + static_cast<unsigned>(i0) * static_cast<unsigned>(ch * 4);
+#pragma unroll
+    for (int j = 0; j < kAPer; ++j) {
+      a_raw[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, off0 + j * a_step, 0, 0));
+      a_win[j] = w_ptr[i0 + kAStride * j];
+    }
+#pragma unroll
+    for (int j = 0; j < kBPer; ++j)
+      b_stage[j] = *reinterpret_cast<const f32x4 *>(b_ptr + static_cast<size_t>(i0 + kBRowsPer * j) * kHopI);
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < kAPer; ++j) {
+      float r = a_raw[j], w = a_win[j];
+      asm volatile("" : "+v"(r), "+v"(w));  // first use of the staged registers stays behind the stage's math
+      As[buf][(a_i + kAStride * j) * BM + a_r] = mul_rn(r, w);  // block[i] = slice[i]*window[i], :480
+    }
+#pragma unroll
+    for (int j = 0; j < kBPer; ++j) {
+      f32x4 b = b_stage[j];
+      asm volatile("" : "+v"(b));
+      *reinterpret_cast<f32x4 *>(&Bs[buf][(b_r + kBRowsPer * j) * BN + b_c4 * 4]) = b;
+    }
+  };
+
+  f32x2 acc[2][TN / 2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < TN / 2; ++c) acc[r][c] = f32x2{0.0f, 0.0f};  // `let mut s = 0.0f32`, :365
+
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+
+  const unsigned a_lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(&As[0][ty * 2]));
+  const unsigned b_lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(&Bs[0][tx * TN]));
+  constexpr int kStages = kFrameI / BK;
+#pragma unroll 1
+  for (int s = 0; s < kStages; ++s) {
+    const int buf = s & 1;
+    load_stage(((s + 1) & (kStages - 1)) * BK);  // (the last iteration re-fetches stage 0 into the idle buffer)
+    const unsigned a_addr = a_lds0 + buf * (BK * BM * 4);
+    const unsigned b_addr = b_lds0 + buf * (BK * BN * 4);
+    SmallOps<TN> ring[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) small_fetch<TN, BM, BN>(ring[d], a_addr, b_addr, d);
+    small_steps<TN, BM, BN, BK, D, 0>(acc, ring, a_addr, b_addr);
+    store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: out[k] = s * norm, :372
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const unsigned row = m0 + ty * 2 + r;
+    if (row >= M) continue;
+    float *dst = coef + static_cast<size_t>(row) * kHopI + n0 + tx * TN;
+    if constexpr (TN == 2) {
+      float2 o;
+      o.x = mul_rn(acc[r][0].x, tb.norm); o.y = mul_rn(acc[r][0].y, tb.norm);
+      *reinterpret_cast<float2 *>(dst) = o;
+    } else {
+      float4 o;
+      o.x = mul_rn(acc[r][0].x, tb.norm); o.y = mul_rn(acc[r][0].y, tb.norm);
+      o.z = mul_rn(acc[r][1].x, tb.norm); o.w = mul_rn(acc[r][1].y, tb.norm);
+      *reinterpret_cast<float4 *>(dst) = o;
+    }
+  }
+}
+
+template <int TN>
+inline hipError_t launch_small(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M, float *coef,
+                               hipStream_t s) {
+  if (M == 0) return hipSuccess;
+  const unsigned m_tiles = (M + 31) / 32;
+  hipLaunchKernelGGL((k_mdct_fwd_small<TN>), dim3(m_tiles * (kHopI / (16 * TN))), dim3(256), 0, s, t, pcm,
+                     static_cast<long long>(frame_begin), M, coef);
+  return hipGetLastError();
+}
+
 template <int BM, int BN, int BK, int TM, int TN, int UNROLL, int MINW>
 inline hipError_t launch(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M,
                          float *coef, hipStream_t s) {
