@@ -995,10 +995,12 @@ hipError_t launch_mdct_forward(const DeviceTables &t, const PcmView &pcm, uint64
   // kernel serves every batch of 4096 rows or more; short clips use 64-row tiles.
   // A clip of a few seconds is latency-bound by one wave's chain of 2048 dependent i-steps, not by
   // throughput, and the length of a step is the lane tile: cut it until every SIMD has a wave of its own
-  // (2 x 2 outputs per lane up to 256 rows, 2 x 4 up to 512; glc_mdct_fwd.hpp k_mdct_fwd_small).
-  if (M <= 256) return k1::launch_small<2>(t, pcm, frame_begin, M, coef, s);
-  if (M <= 512) return k1::launch_small<4>(t, pcm, frame_begin, M, coef, s);
-  if (M < 4096) return k1::launch_sched<64, 128, 16, 4>(t, pcm, frame_begin, M, coef, s);  // short clips: more workgroups
+  // (glc_mdct_fwd.hpp k_mdct_fwd_small: 2 x 2 outputs per lane, then 2 x 4).  Measured against the 4 x 8
+  // kernels (profiles/r03_k1_tune_short_clips.txt): 172 rows 0.058 ms (4 x 8 tile: 0.19), 600 rows 0.10,
+  // 1024 rows 0.11, 1536 rows 0.15; at 2048 rows the 64 x 128 kernel draws level (0.19).
+  if (M <= 640) return k1::launch_small<2>(t, pcm, frame_begin, M, coef, s);
+  if (M <= 1792) return k1::launch_small<4>(t, pcm, frame_begin, M, coef, s);
+  if (M < 4096) return k1::launch_sched<64, 128, 16, 4>(t, pcm, frame_begin, M, coef, s);  // 1793..4095 rows: more workgroups than the 128-row tile gives
   // 512 threads, 4x8 per lane, table tile by LDS-DMA; PCM by one dwordx4 per lane and stage when the
   // channel count divides the tile height, else one dword per (row, sample)
   switch (pcm.ch) {

@@ -707,7 +707,7 @@ def test_long_ragged_streams_and_shards(torch_cuda, ch):
 
 # ---------------------------------------------------------------------------------------
 # Direct coefficient-bit parity of the two hand-scheduled transforms: the
-# launches the benchmark and long streams actually take - k_mdct_fwd_sched (513..4095 rows) and
+# launches the benchmark and long streams actually take - k_mdct_fwd_sched (1793..4095 rows) and
 # the five k_mdct_fwd_dma instantiations (>= 4096 rows; ch 1 / 2 / 4 / 8 = dwordx4 segment loader,
 # 3 = per-row loader) - compared f32 bit for f32 bit with the oracle's mdct_block on windows of
 # frames: the stream start (leading zero padding), a noise burst, the ragged end (partially
@@ -740,7 +740,7 @@ def test_k1_large_launch_coefficient_bits(torch_cuda, ch, kernel):
 
     def launch_and_check(f0, t0, t_count, windows):
         rows = (nf - f0) * ch
-        assert (513 <= rows <= 4095) if kernel == "sched" else rows >= 4096
+        assert (1793 <= rows <= 4095) if kernel == "sched" else rows >= 4096
         lo, hi = t0 * ch, min((t0 + t_count) * ch, x.size)
         d_pcm = torch_cuda.from_numpy(x[lo:hi].copy()).cuda()
         d_coef = torch_cuda.full((rows, 1024), float("nan"), dtype=torch_cuda.float32, device="cuda")
@@ -760,17 +760,18 @@ def test_k1_large_launch_coefficient_bits(torch_cuda, ch, kernel):
     launch_and_check(0, 0, L, [0, nf // 2 - 2, (128 * 3) // ch, nf - W])
     # a shard: frames [f0, nf) from a buffer that holds only [1024 f0 - 512, L)
     f0 = 2 if kernel == "sched" else 3
-    if (nf - f0) * ch >= (513 if kernel == "sched" else 4096):
+    if (nf - f0) * ch >= (1793 if kernel == "sched" else 4096):
         launch_and_check(f0, f0 * 1024 - 512, L - (f0 * 1024 - 512), [f0, nf // 2 - 1, nf - W])
 
 
 def test_k1_small_launch_tile_edges(torch_cuda):
-    """The <= 512-row kernel across its 32-row tile edges and with a partial last tile."""
-    for ch, frames in ((1, 70), (2, 255), (3, 170), (8, 64)):
+    """The short-clip transform (k_mdct_fwd_small: 2 x 2 outputs per lane up to 640 rows, 2 x 4 up to
+    1792) across its 32-row tile edges, with partial last tiles, ragged ends, and at both ends of each range."""
+    for ch, frames in ((1, 70), (2, 255), (3, 170), (8, 64), (2, 320), (1, 641), (2, 500), (3, 597), (8, 224), (5, 300)):
         x, sr = _k1_stream(ch, frames, 7 * ch)
         plan = glc_amd.plan_encode(x.size, ch)
         nf = plan.n_frames
-        assert nf * ch <= 512
+        assert nf * ch <= 1792
         d_pcm = torch_cuda.from_numpy(x).cuda()
         d_coef = torch_cuda.zeros((nf * ch, 1024), dtype=torch_cuda.float32, device="cuda")
         enc = glc_amd.Encoder(sr)
