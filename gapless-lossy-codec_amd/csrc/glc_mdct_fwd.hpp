@@ -512,6 +512,9 @@ inline hipError_t launch_sched(const DeviceTables &t, const PcmView &pcm, uint64
   return hipGetLastError();
 }
 
+#ifndef GLC_K1_A_STRIDE
+#define GLC_K1_A_STRIDE 132  // floats between consecutive i rows of the A tile in LDS (128 = unpadded; tuning: k1_tune)
+#endif
 // ------------------------------------------------------------------------------------------
 // LDS-DMA kernel (128x128 tile, 512 threads, 4x8 outputs per lane, 3-slot LDS ring).
 // The table tile of stage s+2 is copied global -> LDS by `global_load_lds_dwordx4` while stages s
@@ -538,13 +541,18 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
   // fewer cache-line touches in the texture addresser than the per-row loader.
   // 512 threads, 2 workgroups per CU (56 KiB LDS each).
   constexpr int BM = 128, BN = 128, BK = 16, TM = 4, RING = 3;
+  // A rows are kAS floats apart in LDS, 4 more than the tile is wide: the segment loader's four ds_write_b32
+  // per lane put lanes of DIFFERENT i at the same column, and with a stride of 128 floats all of them fall
+  // into one bank (8-way for stereo, 16-way for 4 / 8 channels: SQ_LDS_BANK_CONFLICT was 22 % of the
+  // LDS-array cycles, profiles/r03_k1_pmc_before_prio.txt); the padding spreads them (2-way, which costs nothing).
+  constexpr int kAS = GLC_K1_A_STRIDE;
   constexpr int kThreads = 4 * BM;
   constexpr int kAPer = 4, kAStride = 4;
   constexpr bool kSeg = CH != 0;  // segment loader
   static_assert(!kSeg || CH == 1 || CH == 2 || CH == 4 || CH == 8, "segment loader shapes");
   constexpr int kDma = (BK * BN * 4) / (kThreads * 16);  // table-DMA instructions per thread and stage
   static_assert(kDma == 1, "one table-DMA instruction per thread and stage");
-  __shared__ __attribute__((aligned(16))) float As[RING][BK * BM];
+  __shared__ __attribute__((aligned(16))) float As[RING][BK * kAS];
   __shared__ __attribute__((aligned(16))) float Bs[RING][BK * BN];
   __shared__ __attribute__((aligned(16))) float Ws[kFrameI];
 
@@ -627,14 +635,14 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
       for (int j = 0; j < 4; ++j) {
         const int e = seg_o + j;  // float e of the segment: sample i = e / CH of channel e % CH
         const int ii = e / CH;
-        As[slot][ii * BM + seg_fl * CH + e % CH] = mul_rn(a_seg[j], Ws[i0 + ii]);  // :480
+        As[slot][ii * kAS + seg_fl * CH + e % CH] = mul_rn(a_seg[j], Ws[i0 + ii]);  // :480
       }
       return;
     }
 #pragma unroll
     for (int j = 0; j < kAPer; ++j) {
       const int ii = a_i + kAStride * j;
-      As[slot][ii * BM + a_r] = mul_rn(a_raw[j], Ws[i0 + ii]);  // block[i] = slice[i]*window[i], :480
+      As[slot][ii * kAS + a_r] = mul_rn(a_raw[j], Ws[i0 + ii]);  // block[i] = slice[i]*window[i], :480
     }
   };
   auto wait_staged = [&]() {  // everything this wave has in flight: PCM registers + table DMA of the next stage
@@ -678,7 +686,7 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
   // profiles/r02_k1_tune_mid_stage.txt) - the hand-off is not where the idle issue slots come from -
   // so the simpler protocol (one plain wait on stage-old loads, no exposed fetch) is the one shipped.
   Operands X, Y;
-  lds_fetch4<BM, BN>(X, a_lds0, b_lds0, 0);
+  lds_fetch4<kAS, BN>(X, a_lds0, b_lds0, 0);
   lds_wait4(X);
   if constexpr (STAMP) {
     if (tid == 0) stamps[static_cast<size_t>(blockIdx.x) * 8] = __builtin_amdgcn_s_memrealtime();
@@ -700,14 +708,14 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
       if (tid == 0 && (s & 31) == 0 && s) stamps[static_cast<size_t>(blockIdx.x) * 8 + (s >> 5)] = __builtin_amdgcn_s_memrealtime();
     }
     const int slot = s % 3, nslot = (s + 1) % 3;
-    const unsigned a_addr = a_lds0 + slot * (BK * BM * 4);
+    const unsigned a_addr = a_lds0 + slot * (BK * kAS * 4);
     const unsigned b_addr = b_lds0 + slot * (BK * BN * 4);
-    const unsigned a_next = a_lds0 + nslot * (BK * BM * 4);
+    const unsigned a_next = a_lds0 + nslot * (BK * kAS * 4);
     const unsigned b_next = b_lds0 + nslot * (BK * BN * 4);
 #pragma unroll
     for (int ii = 0; ii < BK / 2; ii += 2) {
-      step4<BM, BN, true>(acc, X, Y, a_addr, b_addr, ii + 1);
-      step4<BM, BN, true>(acc, Y, X, a_addr, b_addr, ii + 2);
+      step4<kAS, BN, true>(acc, X, Y, a_addr, b_addr, ii + 1);
+      step4<kAS, BN, true>(acc, Y, X, a_addr, b_addr, ii + 2);
     }
     // stage s+1: its PCM registers and table DMA (both issued in the middle of stage s-1) have landed
     wait_staged();
@@ -718,9 +726,9 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
     issue_a(((s + 2) & (kStages - 1)) * BK);
 #pragma unroll
     for (int ii = BK / 2; ii < BK; ii += 2) {
-      step4<BM, BN, true>(acc, X, Y, a_addr, b_addr, ii + 1);
-      if (ii + 2 < BK) step4<BM, BN, true>(acc, Y, X, a_addr, b_addr, ii + 2);
-      else step4<BM, BN, true>(acc, Y, X, a_next, b_next, 0);  // the first operands of stage s+1
+      step4<kAS, BN, true>(acc, X, Y, a_addr, b_addr, ii + 1);
+      if (ii + 2 < BK) step4<kAS, BN, true>(acc, Y, X, a_addr, b_addr, ii + 2);
+      else step4<kAS, BN, true>(acc, Y, X, a_next, b_next, 0);  // the first operands of stage s+1
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the wrap-around prefetches
