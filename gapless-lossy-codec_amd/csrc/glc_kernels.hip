@@ -511,39 +511,36 @@ __global__ __launch_bounds__(256) void k_imdct_raw_rows(DecodeRows rows, unsigne
 // share a CU (measured: tools/d1_tune.hip prints the hardware ids).  The kernel ends when its slowest CU
 // does, so units are ranked by work (descending; ties by index, which makes the ranks a permutation)
 // and dealt in a snake over the 256 CU slots: heaviest with lightest.  Units beyond the first 1024
-// follow in descending order (they are dispatched as earlier ones finish: longest first).  One thread
-// per unit, every key compared from LDS; a few microseconds, amortised over the decodes that reuse the
-// plan (tools/d1_tune.hip: apply 80.4 -> 76.3 us at config 2).
+// follow in descending order (they are dispatched as earlier ones finish: longest first).  A few
+// microseconds, amortised over the decodes that reuse the plan (tools/d1_tune.hip: apply 80.4 -> 76.3 us
+// at config 2).
 constexpr unsigned kOrderMaxUnits = 4096;
+// One WAVE per unit: its 64 lanes compare the unit's key with all n keys (each lane a strided share,
+// read straight from L2), a wave reduction gives the rank.  (The first version - one THREAD per unit, every
+// key compared from LDS - took 25 us for 1024 units: four workgroups, one wave per SIMD, 6 K vector
+// instructions each at the single-wave issue rate.)
 __global__ __launch_bounds__(256) void k_imdct_order(const unsigned *__restrict__ plan_work, unsigned n_units,
                                                       unsigned *__restrict__ order) {
-  __shared__ __attribute__((aligned(16))) unsigned s_key[kOrderMaxUnits];
-  const unsigned n4 = (n_units + 3u) & ~3u;
-  for (unsigned i = threadIdx.x; i < n4; i += 256) s_key[i] = i < n_units ? plan_work[i] : 0u;  // padding keys rank below every unit
-  __syncthreads();
-  const unsigned u = blockIdx.x * 256 + threadIdx.x;
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned u = blockIdx.x * 4u + (threadIdx.x >> 6);
   if (u >= n_units) return;
-  const unsigned mine = s_key[u];
-  // rank = units with more work, or equal work and a lower index: key (work, ~index) as one 64-bit compare
-  // would do; two counters keep it in 32-bit ops.  Four keys per LDS read (every lane reads the same
-  // address: a broadcast), eight reads in flight.
-  unsigned above = 0, ties_before = 0;
-  const uint4 *k4 = reinterpret_cast<const uint4 *>(s_key);
-#pragma unroll 8
-  for (unsigned j = 0; j < n4 / 4; ++j) {
-    const uint4 k = k4[j];
-    above += (k.x > mine) + (k.y > mine) + (k.z > mine) + (k.w > mine);
-    const unsigned b = j * 4;
-    ties_before += (k.x == mine && b < u) + (k.y == mine && b + 1 < u) + (k.z == mine && b + 2 < u) + (k.w == mine && b + 3 < u);
+  const unsigned mine = plan_work[u];
+  // rank = units with more work, or equal work and a lower index (ties by index make the ranks a permutation)
+  unsigned cnt = 0;
+  for (unsigned j = lane; j < n_units; j += 64u) {
+    const unsigned k = plan_work[j];
+    cnt += (k > mine || (k == mine && j < u)) ? 1u : 0u;
   }
-  const unsigned rank = above + ties_before;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+  const unsigned rank = cnt;
   unsigned pos = rank;
   if (rank < 1024u) {
     const unsigned round = rank >> 8, p = rank & 255u;
     const unsigned in_round = min(256u, min(n_units, 1024u) - (round << 8));  // the last round may be partial
     pos = (round << 8) + ((round & 1u) ? in_round - 1u - p : p);
   }
-  order[pos] = u;
+  if (lane == 0) order[pos] = u;
 }
 
 // rows (r, r+1) x 8 columns, coefficient pair in SGPRs: the same instruction block as k1::mac2rows
@@ -1096,7 +1093,7 @@ hipError_t launch_imdct_rows(const DeviceTables &t, const DecodeRows &rows, uint
     const bool ranked = n_units > 256 && n_units <= kOrderMaxUnits;
     if (!reuse_plan) {
       hipLaunchKernelGGL(k_imdct_plan, grid, dim3(256), 0, s, rows, row_begin, n_frames, ch, fg0, 2u, hdr, rec, work);
-      if (ranked) hipLaunchKernelGGL(k_imdct_order, dim3((n_units + 255) / 256), dim3(256), 0, s, work, n_units, order);
+      if (ranked) hipLaunchKernelGGL(k_imdct_order, dim3((n_units + 3) / 4), dim3(256), 0, s, work, n_units, order);
     }
     const unsigned *ord = ranked ? order : nullptr;
     if (variant == 2)
