@@ -611,7 +611,8 @@ int glc_frame_raw(const glc_frames *f, uint64_t frame, int16_t *pcm, uint64_t ca
   if (!f || frame >= f->n_frames || !f->raw_tag[frame]) return GLC_EINVAL;
   const uint64_t a = f->raw_begin[frame], b = f->raw_begin[frame + 1];
   if (n) *n = b - a;
-  if (pcm) std::memcpy(pcm, f->raw.data() + a, sizeof(int16_t) * ((b - a) < cap ? (b - a) : cap));
+  const uint64_t take = (b - a) < cap ? (b - a) : cap;
+  if (pcm && take) std::memcpy(pcm, f->raw.data() + a, sizeof(int16_t) * take);  // (Some(vec![]) in an empty pool: no null memcpy)
   return GLC_OK;
 }
 

@@ -1,6 +1,6 @@
 // host_fuzz.cpp — AddressSanitizer + UBSan harness for the host-side parsers and writers of the
-// library (no device code): the .glc container (glc_frames.cpp), the WAV twin (glc_wav.cpp) and
-// the FLAC twin (glc_flac.cpp).  GPU sanitizers are not available on the pool, host ones are, and
+// library (no device code): the .glc container and the structured bridge (glc_frames.cpp), the WAV twin
+// (glc_wav.cpp) and the FLAC twin (glc_flac.cpp).  GPU sanitizers are not available on the pool, host ones are, and
 // these are the functions that read files a user did not write.
 //
 // Build (tests/test_host.py does this):
@@ -147,6 +147,123 @@ static void fuzz_glc(const std::string &tmp) {
   }
 }
 
+// ---- the structured bridge: flat view, from_parts / from_gather on hostile arrays ------------------
+static void fuzz_bridge() {
+  std::vector<uint8_t> good = make_glc(1 + static_cast<unsigned>(below(3)), 1 + static_cast<unsigned>(below(6)));
+  if (good.empty()) return;
+  glc_frames *fr = nullptr;
+  REQUIRE(glc_deserialize(good.data(), good.size(), &fr) == GLC_OK);
+  glc_frames_view v;
+  REQUIRE(glc_frames_get_view(fr, &v) == GLC_OK);
+  // own copies of every array, so that a mutation cannot touch the library's object
+  std::vector<uint64_t> list_begin(v.list_begin, v.list_begin + v.n_frames + 1), list_off(v.list_off, v.list_off + v.n_lists + 1),
+      scale_begin(v.scale_begin, v.scale_begin + v.n_frames + 1), raw_begin(v.raw_begin, v.raw_begin + v.n_frames + 1);
+  std::vector<uint32_t> pairs(v.pairs, v.pairs + v.n_pairs);
+  std::vector<float> scales(v.scales, v.scales + v.n_scales);
+  std::vector<uint8_t> raw_tag(v.raw_tag, v.raw_tag + v.n_frames);
+  std::vector<int16_t> raw(v.raw, v.raw + v.n_raw);
+  glc_frames_view p = v;
+  auto point = [&] {
+    p.list_begin = list_begin.data(), p.list_off = list_off.data(), p.pairs = pairs.data(), p.scale_begin = scale_begin.data();
+    p.scales = scales.data(), p.raw_tag = raw_tag.data(), p.raw_begin = raw_begin.data(), p.raw = raw.data();
+  };
+  point();
+  {  // the unmodified parts rebuild the same stream, byte for byte, under a caller's id
+    glc_frames *back = nullptr;
+    REQUIRE(glc_frames_from_parts(&p, 77, &back) == GLC_OK && glc_frames_stream_id(back) == 77);
+    std::vector<uint8_t> again(glc_serialized_size(back));
+    uint64_t w = 0;
+    REQUIRE(glc_serialize(back, again.data(), again.size(), &w) == GLC_OK && again == good);
+    glc_frames_free(back);
+    REQUIRE(glc_frames_from_parts(&p, 1ull << 63, &back) == GLC_EINVAL && back == nullptr);
+  }
+  for (int round = 0; round < 30; ++round) {
+    // hostile offsets / counts / tags: the constructor validates before it reads through them
+    glc_frames_view q = p;
+    std::vector<uint64_t> lb = list_begin, lo = list_off, sb = scale_begin, rb = raw_begin;
+    std::vector<uint8_t> rt = raw_tag;
+    auto wreck = [&](std::vector<uint64_t> &a) {
+      if (a.empty()) return;
+      uint64_t &x = a[below(a.size())];
+      switch (below(4)) {
+        case 0: x += 1 + below(5); break;
+        case 1: x = x ? x - 1 : 7; break;
+        case 2: x = rnd() >> below(64); break;
+        default: x = ~0ull - below(9); break;
+      }
+    };
+    switch (below(8)) {
+      case 0: wreck(lb); break;
+      case 1: wreck(lo); break;
+      case 2: wreck(sb); break;
+      case 3: wreck(rb); break;
+      case 4: if (!rt.empty()) rt[below(rt.size())] = static_cast<uint8_t>(below(4)); break;
+      case 5: q.n_pairs += below(2) ? 1 : ~0ull >> below(40); break;
+      case 6: q.n_lists = below(2) ? q.n_lists + 1 : q.n_lists ? q.n_lists - 1 : 3; break;
+      default: q.n_raw = below(2) ? q.n_raw + 2 : q.n_raw / 2; break;
+    }
+    // (counts larger than the arrays are only legal to TRY when the offsets veto them first: n_lists / n_pairs /
+    //  n_raw are checked against the closing offsets, which live inside the arrays we own)
+    if (q.n_lists > p.n_lists) q.n_lists = p.n_lists;   // list_off has n_lists + 1 entries: reading beyond is the caller's bug, not input
+    q.list_begin = lb.data(), q.list_off = lo.data(), q.scale_begin = sb.data(), q.raw_begin = rb.data(), q.raw_tag = rt.data();
+    glc_frames *out = nullptr;
+    const int rc = glc_frames_from_parts(&q, 0, &out);
+    if (rc == GLC_OK) {  // whatever is accepted is a well-formed stream: it serialises, re-parses and can be walked
+      std::vector<uint8_t> bytes(glc_serialized_size(out));
+      uint64_t w = 0;
+      REQUIRE(glc_serialize(out, bytes.data(), bytes.size(), &w) == GLC_OK);
+      glc_frames *re = nullptr;
+      REQUIRE(glc_deserialize(bytes.data(), bytes.size(), &re) == GLC_OK);
+      touch(re);
+      glc_frames_free(re);
+      touch(out);
+      glc_frames_free(out);
+    } else {
+      REQUIRE(out == nullptr && (rc == GLC_EFORMAT || rc == GLC_EINVAL || rc == GLC_ENOMEM));
+    }
+  }
+  {  // the gather form from per-vector copies: same bytes; null vectors with non-zero lengths are refused
+    std::vector<std::vector<uint32_t>> lists;
+    std::vector<std::vector<float>> sc(v.n_frames);
+    std::vector<std::vector<int16_t>> rw(v.n_frames);
+    std::vector<uint32_t> lists_per(v.n_frames), list_len, scales_per(v.n_frames);
+    std::vector<const void *> list_ptr;
+    std::vector<const float *> scale_ptr(v.n_frames);
+    std::vector<const int16_t *> raw_ptr(v.n_frames);
+    std::vector<uint64_t> raw_len(v.n_frames);
+    for (uint64_t f = 0; f < v.n_frames; ++f) {
+      lists_per[f] = static_cast<uint32_t>(list_begin[f + 1] - list_begin[f]);
+      for (uint64_t l = list_begin[f]; l < list_begin[f + 1]; ++l) lists.emplace_back(pairs.begin() + list_off[l], pairs.begin() + list_off[l + 1]);
+      sc[f].assign(scales.begin() + scale_begin[f], scales.begin() + scale_begin[f + 1]);
+      scales_per[f] = static_cast<uint32_t>(sc[f].size());
+      if (raw_tag[f]) rw[f].assign(raw.begin() + raw_begin[f], raw.begin() + raw_begin[f + 1]);
+    }
+    static const int16_t none[1] = {0};
+    for (auto &l : lists) list_ptr.push_back(l.data()), list_len.push_back(static_cast<uint32_t>(l.size()));
+    for (uint64_t f = 0; f < v.n_frames; ++f) {
+      scale_ptr[f] = sc[f].data();
+      raw_ptr[f] = raw_tag[f] ? (rw[f].empty() ? none : rw[f].data()) : nullptr;
+      raw_len[f] = rw[f].size();
+    }
+    glc_frames_gather g{};
+    g.sample_rate = v.sample_rate, g.channels = v.channels, g.total_samples = v.total_samples, g.encoder_delay = v.encoder_delay;
+    g.padding = v.padding, g.original_length = v.original_length, g.n_frames = v.n_frames;
+    g.lists_per_frame = lists_per.data(), g.list_ptr = list_ptr.data(), g.list_len = list_len.data();
+    g.scales_per_frame = scales_per.data(), g.scale_ptr = scale_ptr.data(), g.raw_ptr = raw_ptr.data(), g.raw_len = raw_len.data();
+    glc_frames *back = nullptr;
+    REQUIRE(glc_frames_from_gather(&g, 5, &back) == GLC_OK);
+    std::vector<uint8_t> again(glc_serialized_size(back));
+    uint64_t w = 0;
+    REQUIRE(glc_serialize(back, again.data(), again.size(), &w) == GLC_OK && again == good);
+    glc_frames_free(back);
+    if (!list_ptr.empty() && list_len[0]) {
+      list_ptr[0] = nullptr;
+      REQUIRE(glc_frames_from_gather(&g, 0, &back) == GLC_EINVAL && back == nullptr);
+    }
+  }
+  glc_frames_free(fr);
+}
+
 // ---- WAV ----------------------------------------------------------------------------------------
 static void fuzz_wav(const std::string &tmp) {
   const std::string path = tmp + "/fuzz.wav";
@@ -256,6 +373,7 @@ int main(int argc, char **argv) {
   uint64_t rounds = 0;
   while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
     fuzz_glc(tmp);
+    fuzz_bridge();
     fuzz_wav(tmp);
     fuzz_flac();
     ++rounds;
