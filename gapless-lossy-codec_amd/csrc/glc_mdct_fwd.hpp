@@ -14,13 +14,17 @@
 //                      4x8 outputs per lane, table tile copied global -> LDS by LDS-DMA two stages ahead
 //                      (3-slot ring), one counted vmcnt wait per stage; PCM tile by one dwordx4 per lane
 //                      and stage when the stream has 1 / 2 / 4 / 8 channels (CH), one dword per
-//                      (row, sample) otherwise (CH = 0).
-//   k_mdct_fwd_sched   513..4095 rows, as <64,128,16,4>: 64x128 tile, 256 threads, hand-scheduled
+//                      (row, sample) otherwise (CH = 0); issue priority lowered by quarter of the i loop
+//                      (PRIO = 1), A rows padded in LDS (GLC_K1_A_STRIDE).
+//   k_mdct_fwd_sched   1793..4095 rows, as <64,128,16,4>: 64x128 tile, 256 threads, hand-scheduled
 //                      inline-asm i-steps (step4), LDS operand prefetch, XCD-aware tile map, register
 //                      staging, classic double buffer.
-//   k_mdct_fwd         up to 512 rows, as <32,64,32,4,4,4,2>: the same tiling left to hipcc's scheduler
-//                      (short clips: the latency of one workgroup's 2048-step chain is everything, and
-//                      smaller lane tiles shorten the step).
+//   k_mdct_fwd_small   up to 1792 rows: 2x2 / 2x4 outputs per lane on 32x32 / 32x64 tiles, 256 threads,
+//                      hand-scheduled with a register ring of LDS operands and counted lgkmcnt waits
+//                      (short clips: one wave's 2048-step chain is everything; the step is the lane tile).
+//   k_mdct_fwd         the same tiling left to hipcc's scheduler: no longer instantiated by the library
+//                      (round 2 used <32,64,32,4,4,4,2> for <= 512 rows); kept as the plainest statement
+//                      of the loop and for tools/k1_tune.hip.
 //   mac2rows           the 2-row x 8-column multiply/add block; also the entry step of D1 (k_imdct_chan).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -765,7 +769,7 @@ inline hipError_t launch_dma(const DeviceTables &t, const PcmView &pcm, uint64_t
 
 
 // ------------------------------------------------------------------------------------------
-// Short clips (<= 512 rows: BASELINE config 1 and every clip of the reference's own tests).  A launch
+// Short clips (<= 1792 rows: BASELINE config 1 and every clip of the reference's own tests).  A launch
 // this small cannot fill the chip; what it costs is ONE wave's chain of 2048 dependent i-steps, and the
 // length of a step is the lane tile: 128 VALU cycles for 4 x 8 outputs, 16 for 2 x 2.  So the tile is
 // cut until every SIMD of the chip has a wave of its own - 2 x 2 outputs per lane up to 256 rows, 2 x 4

@@ -95,7 +95,7 @@ def main():
     fw = factors["calib_write_b128"]["counter_bytes_per_true_byte"]
     k1 = kernels["K1"]
     out = {
-        "kernel": "glc::k1::k_mdct_fwd_dma<4, 2> (128x128 tile, 512 threads, table tile by LDS-DMA, PCM by dwordx4 segments)",
+        "kernel": "glc::k1::k_mdct_fwd_dma<4, 2, 1, false> (128x128 tile, 512 threads, table tile by LDS-DMA, PCM by dwordx4 segments)",
         "commit": args.commit,
         "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --steps 10, corrected by the "
                   "factors tools/fetch_calib.hip measures for K1's own access patterns in the same session",
