@@ -698,7 +698,14 @@ void k_mdct_fwd_dma(DeviceTables tb, PcmView pcm, long long frame_begin, unsigne
   if constexpr (PRIO != 0) __builtin_amdgcn_s_setprio(3);
 #pragma unroll 1
   for (int s = 0; s < kStages; ++s) {
-    if constexpr (PRIO != 0) {
+    if constexpr (PRIO >= 5) {
+      // a ladder that gets finer towards the end (the tail of a launch is as long as its last rung):
+      //   5: [0, 64) 3, [64, 96) 2, [96, 112) 1, [112, 128) 0      6: [0, 48) 3, [48, 96) 2, [96, 120) 1, [120, 128) 0
+      constexpr int b1 = PRIO == 5 ? 64 : 48, b2 = 96, b3 = PRIO == 5 ? 112 : 120;
+      if (s == b1) __builtin_amdgcn_s_setprio(2);
+      else if (s == b2) __builtin_amdgcn_s_setprio(1);
+      else if (s == b3) __builtin_amdgcn_s_setprio(0);
+    } else if constexpr (PRIO != 0) {
       constexpr int kShift = PRIO == 1 ? 5 : PRIO == 2 ? 1 : PRIO == 3 ? 2 : 3;  // stages per level = 1 << kShift
       if ((s & ((1 << kShift) - 1)) == 0) {
         const int level = (s >> kShift) & 3;

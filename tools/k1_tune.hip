@@ -223,9 +223,14 @@ int main(int argc, char **argv) {
       Variant{"dma segment loader, PRIO 2: four levels cycling every 8 stages", dma_prio<4, 2, 2>},
       Variant{"dma segment loader, PRIO 3: four levels cycling every 16 stages", dma_prio<4, 2, 3>},
       Variant{"dma segment loader, PRIO 4: four levels cycling every 32 stages", dma_prio<4, 2, 4>},
+      Variant{"dma segment loader, PRIO 5: rungs of 64, 32, 16, 16 stages", dma_prio<4, 2, 5>},
+      Variant{"dma segment loader, PRIO 6: rungs of 48, 48, 24, 8 stages", dma_prio<4, 2, 6>},
       Variant{"SHIPPED dma, segment loader (PRIO 0, again)", dma_shipped<4, 2>},
       Variant{"dma segment loader, PRIO 1 (again)", dma_prio<4, 2, 1>},
       Variant{"dma segment loader, PRIO 3 (again)", dma_prio<4, 2, 3>},
+      Variant{"dma segment loader, PRIO 5 (again)", dma_prio<4, 2, 5>},
+      Variant{"dma segment loader, PRIO 6 (again)", dma_prio<4, 2, 6>},
+      Variant{"dma segment loader, PRIO 1 (third time)", dma_prio<4, 2, 1>},
       // tuning variants (tools/k1_variants.hpp)
       Variant{"dma segment loader, round-1 protocol: end-of-stage hand-off, counted vmcnt(1)", k1x::launch_dma<4, 0, 128, 2, 0>},
       Variant{"dma segment loader, issue priority alternates between a CU's two workgroups every stage", k1x::launch_dma<4, 0, 128, 2, -1>},
