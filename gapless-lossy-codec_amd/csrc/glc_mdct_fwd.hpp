@@ -786,6 +786,9 @@ inline hipError_t launch_dma(const DeviceTables &t, const PcmView &pcm, uint64_t
 // order), the next stage's global loads are in flight during the stage and only waited for at its end.
 // (Round 2 left this range to hipcc on a 4 x 4 lane tile: 129 VGPRs + 80 B of scratch, 0.13 ms at 172 rows.)
 // ------------------------------------------------------------------------------------------
+#ifndef GLC_SMALL_PAIR
+#define GLC_SMALL_PAIR 1  // k_mdct_fwd_small waits for its LDS operands once per two i-steps (tuning: k1_tune)
+#endif
 #ifndef GLC_SMALL_BK
 #define GLC_SMALL_BK 32  // i-steps per LDS stage of k_mdct_fwd_small (64 measured 4 % slower: gpurun r3d2)
 #endif
@@ -858,12 +861,29 @@ template <int TN, int BM, int BN, int BK, int D, int II>
 __device__ __forceinline__ void small_steps(f32x2 (&acc)[2][TN / 2], SmallOps<TN> (&ring)[D], unsigned a_addr, unsigned b_addr) {
   if constexpr (II < BK) {
     constexpr int R = 1 + TN / 2;
+#if GLC_SMALL_PAIR
+    // two i-steps per wait: one s_waitcnt and one burst of LDS reads per 2 x 4 vector ops
+    static_assert(BK % 2 == 0 && D % 2 == 0, "pairs");
+    constexpr int younger = II + D <= BK ? D - 2 : BK - 2 - II;  // steps behind II + 1 still in flight
+    static_assert(younger * R <= 15, "lgkmcnt is a 4-bit counter");
+    small_wait<TN, younger * R>(ring[(II + 1) % D]);
+    asm volatile("" : "+v"(ring[II % D].a), "+v"(ring[II % D].b[0]));  // (II landed before II + 1: LDS returns in order)
+    if constexpr (TN == 4) asm volatile("" : "+v"(ring[II % D].b[1]));
+    small_mac<TN>(acc, ring[II % D]);
+    small_mac<TN>(acc, ring[(II + 1) % D]);
+    if constexpr (II + D < BK) {
+      small_fetch<TN, BM, BN>(ring[II % D], a_addr, b_addr, II + D);
+      small_fetch<TN, BM, BN>(ring[(II + 1) % D], a_addr, b_addr, II + D + 1);
+    }
+    small_steps<TN, BM, BN, BK, D, II + 2>(acc, ring, a_addr, b_addr);
+#else
     constexpr int younger = II + D <= BK ? D - 1 : BK - 1 - II;
     static_assert(younger * R <= 15, "lgkmcnt is a 4-bit counter");
     small_wait<TN, younger * R>(ring[II % D]);
     small_mac<TN>(acc, ring[II % D]);
     if constexpr (II + D < BK) small_fetch<TN, BM, BN>(ring[II % D], a_addr, b_addr, II + D);
     small_steps<TN, BM, BN, BK, D, II + 1>(acc, ring, a_addr, b_addr);
+#endif
   }
 }
 
