@@ -254,7 +254,7 @@ def main():
     L.glc_debug_clock_probe_begin.argtypes = [C.c_void_p, C.c_uint32]
     L.glc_debug_clock_probe_end.restype = C.c_int
     L.glc_debug_clock_probe_end.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
-    for _ in range(10):
+    for _ in range(args.spinup if dist_on else 10):   # (the gather and its host-side assembly let the device clock down)
         step()
     k1()
     # the clock the chip HOLDS under this kernel: one sleeping wave reads the shader-cycle counter against
