@@ -178,7 +178,10 @@ struct glc_ctx {
 
 namespace {
 
-constexpr uint64_t kEncodeChunkFrames = 4096;  // rows per K1/K2/K3 round: coef stays MALL-sized
+constexpr uint64_t kEncodeChunkFrames = 4096;  // frames per K1/K2/K3 round: coef stays MALL-sized
+// ... of at least 8192 rows: a 128 x 128-tile launch of 4096 rows is one workgroup per CU, two waves per
+// SIMD (mono, k1_tune: 27.1 T MAC/s at 4096 rows, 30.8 T at 8192)
+inline uint64_t encode_chunk_frames(uint32_t ch) { return ch == 1 ? 2 * kEncodeChunkFrames : kEncodeChunkFrames; }
 constexpr uint64_t kDecodeChunkFrames = 4096;
 
 constexpr uint32_t kPlanGroups = 2048;  // (group, channel) units per D1 batch: 135 MB of workspace
@@ -442,7 +445,7 @@ static int encode_range_on(glc_ctx *ctx, hipStream_t stream, DevBuf &coef_ws, co
   const uint64_t rec = glc::record_bytes(ch);
   glc::PcmView view{d_pcm, t0, t_count, n_samples, ch};
   uint8_t *recs = static_cast<uint8_t *>(d_records);
-  const uint64_t chunk = d_coeffs ? (frame_end - frame_begin ? frame_end - frame_begin : 1) : kEncodeChunkFrames;
+  const uint64_t chunk = d_coeffs ? (frame_end - frame_begin ? frame_end - frame_begin : 1) : encode_chunk_frames(ch);
   if (!d_coeffs) {
     const uint64_t rows = std::min<uint64_t>(chunk, frame_end - frame_begin) * ch;
     GLC_HIP(ctx, coef_ws.reserve(std::max<size_t>(rows, 1) * glc::kHop * sizeof(float)));
@@ -682,7 +685,7 @@ int glc_encode_hooked(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16
     uint64_t blob_off = 0;
     for (uint64_t f = 0, nf = 0; f < plan.n_frames; f += nf) {
       const uint64_t left = plan.n_frames - f;
-      nf = std::min<uint64_t>(f < opening ? piece : kEncodeChunkFrames, left);
+      nf = std::min<uint64_t>(f < opening ? piece : encode_chunk_frames(ch), left);
       if (left - nf < piece / 2) nf = left;  // no round for a remainder of less than half a piece
       // (Measured and dropped, round 3: cutting the END of a stream in halves - .. 2048, 1024, 512, 512 frames -
       // so that the last, unhidden transform is a short one: 1.045 ms against 1.02 at config 2; a round

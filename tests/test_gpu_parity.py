@@ -1150,3 +1150,29 @@ def test_torch_and_library_share_one_hip_runtime(torch_cuda):
     enc.set_stream(s.cuda_stream)   # refused (GlcError) if a second runtime were mapped
     assert glc_amd.lib.glc_ctx_stream(enc._h) == s.cuda_stream
     enc.set_stream(0)
+
+
+def test_mono_stream_across_its_8192_frame_chunks(torch_cuda):
+    """A mono launch of 4096 rows would leave every CU one workgroup (two waves per SIMD), so mono streams
+    are encoded in chunks of 8192 frames: a stream of two chunks + a ragged rest, through glc_encode (rounds),
+    glc_encode_range_device (chunks alternating between two streams) and a shard that starts inside chunk 2,
+    against the oracle."""
+    torch = torch_cuda
+    sr, ch, frames = 48000, 1, 2 * 8192 + 301
+    rng = np.random.default_rng(2024)
+    t = np.arange(frames * 1024, dtype=np.float64)
+    x = (0.3 * np.sin(2 * np.pi * 441.0 * t / sr) + 0.1 * np.sin(2 * np.pi * 5003.0 * t / sr)).astype(np.float32)
+    for f in (8190, 8191, 8192, 16383, 16384):           # noise bursts (raw frames) on both sides of the chunk edges
+        x[f * 1024:(f + 1) * 1024] = rng.standard_normal(1024).astype(np.float32) * 0.3
+    x = x[:-77]
+    ref = O.encode(x, sr, ch, taps=True)
+    assert ref.n_frames > 2 * 8192 and ref.is_raw.sum() >= 4
+    assert glc_amd.Encoder(sr).encode(x, ch).to_bytes() == ref.glc
+    whole, _ = device_encode(torch, x, sr, ch, want_coeffs=False)
+    assert glc_amd.EncodedAudio.from_records(sr, x.size, ch, whole).to_bytes() == ref.glc
+    plan = glc_amd.plan_encode(x.size, ch)
+    rec = glc_amd.lib.glc_record_bytes(ch)
+    f0 = 8192 + 5
+    t0 = f0 * 1024 - 512
+    part, _ = device_encode(torch, x, sr, ch, f0, plan.n_frames, t0, plan.per_channel - t0, want_coeffs=False)
+    assert np.array_equal(part, whole[f0 * rec:])
