@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_PEAK_TFLOPS = 157.3           # f32 vector peak with FMA = 2 flop (MI355X_MICROARCH.md)
 F32_UNFUSED_TFLOPS = F32_PEAK_TFLOPS / 2.0  # separately rounded mul + add: one flop per issue slot
 K1_KERNEL = "glc::k1::k_mdct_fwd_dma<4, 2, 1, false>"   # name in rocprofv3's kernel trace (segment loader for stereo, priority schedule)
-D1_KERNEL = "glc::k_imdct_plan + glc::k_imdct_apply<true, true>"
+D1_KERNEL = "glc::k_imdct_apply<true, true, true> on the kept plan (first decode of a stream: + k_imdct_plan + k_imdct_order)"
 
 
 def make_shard_pcm(np, rank, world):
@@ -407,10 +407,16 @@ def main():
         d_ms = (time.perf_counter() - t_d0) * 1e3 / reps
         for _ in range(20):
             dec.imdct_device(ea_d, 0, FRAMES_PER_GPU, d_blk.data_ptr())
+        d1_probe = L.glc_debug_clock_probe_begin(dec._h, int(0.6 * reps * 70)) == 0   # ~70 us per launch
         dec.timer_begin()
         for _ in range(reps):
             dec.imdct_device(ea_d, 0, FRAMES_PER_GPU, d_blk.data_ptr())
         d1_ms = dec.timer_end() / reps
+        d1_clock = None
+        if d1_probe:
+            g = C.c_float()
+            if L.glc_debug_clock_probe_end(dec._h, C.byref(g)) == 0 and 0.3 < g.value < 3.5:
+                d1_clock = float(g.value)
         total_nnz = int(ea_d.info().total_nnz)
         nnz_row = total_nnz / (FRAMES_PER_GPU * CH)
         d1_tflops = total_nnz * 2048.0 * 2.0 / (d1_ms * 1e-3) / 1e12
@@ -419,6 +425,9 @@ def main():
                   "roofline": {"bound": "valu", "kernel": D1_KERNEL, "achieved": round(d1_tflops, 3),
                                "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(d1_tflops / F32_PEAK_TFLOPS, 4),
                                "frac_of_unfused_ceiling": round(d1_tflops / F32_UNFUSED_TFLOPS, 4),
+                               "clock_ghz_held": round(d1_clock, 3) if d1_clock else None,
+                               "frac_of_unfused_ceiling_at_held_clock":
+                                   round(d1_tflops / (F32_UNFUSED_TFLOPS * d1_clock / 2.4), 4) if d1_clock else None,
                                "ms_per_launch": round(d1_ms, 4),
                                "flop": "2 x 2048 x stored non-zeros (adding the +0.0 products of absent "
                                        "coefficients is the identity, so they are not work)"},
