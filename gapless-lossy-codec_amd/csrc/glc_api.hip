@@ -1390,7 +1390,8 @@ int glc_imdct_device(glc_ctx *ctx, const glc_frames *in, uint64_t frame_begin, u
 }
 
 int glc_debug_set_imdct_variant(glc_ctx *ctx, int variant) {
-  if (!ctx || variant < 0 || variant > 4) return fail(ctx, GLC_EINVAL, "glc_debug_set_imdct_variant: variant must be 0..4");
+  if (!ctx || variant < 0 || variant > 6) return fail(ctx, GLC_EINVAL, "glc_debug_set_imdct_variant: variant must be 0..6");
+  if (variant != ctx->d1_variant) ctx->plan_uid = 0;  // variants 5 / 6 deal the units differently: the kept order is not theirs
   ctx->d1_variant = variant;
   return GLC_OK;
 }

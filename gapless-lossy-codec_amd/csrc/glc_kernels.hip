@@ -520,10 +520,19 @@ constexpr unsigned kOrderMaxUnits = 4096;
 // key compared from LDS - took 25 us for 1024 units: four workgroups, one wave per SIMD, 6 K vector
 // instructions each at the single-wave issue rate.)
 __global__ __launch_bounds__(256) void k_imdct_order(const unsigned *__restrict__ plan_work, unsigned n_units,
-                                                      unsigned *__restrict__ order) {
+                                                      unsigned *__restrict__ order, unsigned ch, unsigned neighbours) {
   const unsigned lane = threadIdx.x & 63u;
   const unsigned u = blockIdx.x * 4u + (threadIdx.x >> 6);
   if (u >= n_units) return;
+  if (neighbours) {
+    // (include/glc_debug.h variant 5, measurement only) the units that share a CU are consecutive frame
+    // groups of one channel - similar unions, similar pace: they find each other's table rows in the CU's L1
+    const unsigned n_fg = n_units / ch, rounds = n_units >> 8;
+    const unsigned fg = u / ch, c = u - fg * ch;
+    const unsigned v = c * n_fg + fg;  // channel-major
+    if (lane == 0) order[(v % rounds) * 256u + v / rounds] = u;
+    return;
+  }
   const unsigned mine = plan_work[u];
   // rank = units with more work, or equal work and a lower index (ties by index make the ranks a permutation)
   unsigned cnt = 0;
@@ -1093,9 +1102,11 @@ hipError_t launch_imdct_rows(const DeviceTables &t, const DecodeRows &rows, uint
     const bool ranked = n_units > 256 && n_units <= kOrderMaxUnits;
     if (!reuse_plan) {
       hipLaunchKernelGGL(k_imdct_plan, grid, dim3(256), 0, s, rows, row_begin, n_frames, ch, fg0, 2u, hdr, rec, work);
-      if (ranked) hipLaunchKernelGGL(k_imdct_order, dim3((n_units + 3) / 4), dim3(256), 0, s, work, n_units, order);
+      const unsigned neighbours = variant == 5 && n_units % 256 == 0 && n_units % ch == 0 ? 1u : 0u;
+      if (ranked && variant != 6)
+        hipLaunchKernelGGL(k_imdct_order, dim3((n_units + 3) / 4), dim3(256), 0, s, work, n_units, order, ch, neighbours);
     }
-    const unsigned *ord = ranked ? order : nullptr;
+    const unsigned *ord = ranked && variant != 6 ? order : nullptr;
     if (variant == 2)
       hipLaunchKernelGGL(k_imdct_apply<false>, grid, dim3(256), 0, s, t, hdr, rec, ord, n_frames, ch, fg0, n_units, blocks);
     else if (variant == 4)

@@ -21,6 +21,9 @@ extern "C" {
  *   2  plan + apply without the skip (every row takes every union entry)
  *   3  plan + apply without the issue-priority schedule (waves of a SIMD finish one after the other)
  *   4  plan + apply skipping absent rows only in pairs (both rows of a pair lack the entry)
+ *   5  the shipped kernels, units dealt so that the four which share a CU are consecutive frame groups of
+ *      one channel (L1 reuse of table rows) instead of being ranked by work   (placement: speed only)
+ *   6  the shipped kernels in the natural unit order with the channel rotated per round (round 2's placement)
  * All of them produce the same bits; tools/soak_decode.py checks that on random streams. */
 int glc_debug_set_imdct_variant(glc_ctx *ctx, int variant);
 
