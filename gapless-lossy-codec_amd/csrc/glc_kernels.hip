@@ -778,30 +778,42 @@ void k_imdct_apply(DeviceTables tb, const unsigned *__restrict__ plan_hdr, const
 // hop h = second half of frame h-1 (+0.0 before the first frame) + first half of frame h; the
 // hop after the last frame is the bare overlap tail (no add, src/codec.rs:722-729).
 // ------------------------------------------------------------------------------------------
+// One workgroup row (blockIdx.y) per hop, a float4 of interleaved output per thread: 32-bit index
+// arithmetic (CH = 1 / 2 / 4 / 8: shifts; CH = 0: one 32-bit division per sample), coalesced 16-byte
+// stores, each block plane read in runs of consecutive samples.  (Round 2's kernel walked the output
+// with a 64-bit grid-stride index: two 64-bit divisions per sample - 20 us at config 2, as long as the
+// 100 MB it moves take at Infinity-Cache speed.)
+template <int CH, bool VEC>
 __global__ __launch_bounds__(256) void k_overlap_add(const float *__restrict__ blocks, long long blk_frame0,
                                                       unsigned long long n_frames, unsigned ch,
-                                                      unsigned long long hop_begin,
-                                                      unsigned long long n_out, float *__restrict__ out) {
-  const unsigned long long per_hop = static_cast<unsigned long long>(kHopI) * ch;
-  for (unsigned long long o = blockIdx.x * 256ull + threadIdx.x; o < n_out;
-       o += static_cast<unsigned long long>(gridDim.x) * 256ull) {
-    const unsigned long long h = hop_begin + o / per_hop;
-    const unsigned rem = static_cast<unsigned>(o % per_hop);
-    const unsigned i = rem / ch, c = rem % ch;
-    float prev = 0.0f;  // overlap starts as +0.0, :601
-    if (h >= 1) {
-      const long long slot = static_cast<long long>(h) - 1 - blk_frame0;
-      prev = blocks[(static_cast<size_t>(slot) * ch + c) * kFrameI + kHopI + i];
-    }
-    float v;
-    if (h < n_frames) {
-      const long long slot = static_cast<long long>(h) - blk_frame0;
-      const float cur = blocks[(static_cast<size_t>(slot) * ch + c) * kFrameI + i];
-      v = add_rn(prev, cur);  // :695
-    } else {
-      v = prev;  // :727
-    }
-    out[o] = v;
+                                                      unsigned long long hop_begin, float *__restrict__ out) {
+  const unsigned per_hop = static_cast<unsigned>(kHopI) * ch;
+  const unsigned o0 = (blockIdx.x * 256u + threadIdx.x) * 4u;  // first of this thread's 4 outputs inside the hop
+  if (o0 >= per_hop) return;
+  const unsigned long long h = hop_begin + blockIdx.y;
+  const bool has_prev = h >= 1, has_cur = h < n_frames;
+  // frame h-1 (second half) and frame h (first half) of the ring: [slot][ch][2048]
+  const float *prev = blocks + (static_cast<size_t>(static_cast<long long>(h) - 1 - blk_frame0) * ch) * kFrameI + kHopI;
+  const float *cur = blocks + (static_cast<size_t>(static_cast<long long>(h) - blk_frame0) * ch) * kFrameI;
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned o = o0 + e;
+    unsigned i, c;
+    if constexpr (CH == 1) i = o, c = 0;
+    else if constexpr (CH == 2) i = o >> 1, c = o & 1u;
+    else if constexpr (CH == 4) i = o >> 2, c = o & 3u;
+    else if constexpr (CH == 8) i = o >> 3, c = o & 7u;
+    else i = o / ch, c = o - i * ch;
+    const size_t at = static_cast<size_t>(c) * kFrameI + i;
+    const float p = has_prev ? prev[at] : 0.0f;  // overlap starts as +0.0, :601
+    v[e] = has_cur ? add_rn(p, cur[at]) : p;      // :695 / the bare tail, :727
+  }
+  float *dst = out + static_cast<size_t>(blockIdx.y) * per_hop + o0;
+  if constexpr (VEC) {
+    *reinterpret_cast<float4 *>(dst) = float4{v[0], v[1], v[2], v[3]};
+  } else {  // a destination that is only 4-byte aligned (glc_decode_range_device takes any device pointer)
+    dst[0] = v[0], dst[1] = v[1], dst[2] = v[2], dst[3] = v[3];
   }
 }
 
@@ -1122,12 +1134,27 @@ hipError_t launch_imdct_rows(const DeviceTables &t, const DecodeRows &rows, uint
 hipError_t launch_overlap_add(const float *blocks, int64_t blk_frame0, uint64_t n_frames, uint32_t ch,
                               uint64_t hop_begin, uint64_t hop_end, float *out, hipStream_t s) {
   if (hop_end <= hop_begin) return hipSuccess;
-  const unsigned long long n_out = (hop_end - hop_begin) * 1024ull * ch;
-  unsigned long long blocks_needed = (n_out + 255) / 256;
-  const unsigned grid = static_cast<unsigned>(blocks_needed < 8192 ? blocks_needed : 8192);
-  hipLaunchKernelGGL(k_overlap_add, dim3(grid), dim3(256), 0, s, blocks,
-                     static_cast<long long>(blk_frame0), static_cast<unsigned long long>(n_frames), ch,
-                     static_cast<unsigned long long>(hop_begin), n_out, out);
+  const unsigned per_hop = 1024u * ch;
+  const unsigned bx = (per_hop / 4u + 255u) / 256u;  // float4s per hop over 256 threads
+  // blockIdx.y is 16 bits wide: hops in slabs of 32768 (every caller stays far below: rounds of <= 4097 hops)
+  for (uint64_t h0 = hop_begin; h0 < hop_end; h0 += 32768) {
+    const unsigned nh = static_cast<unsigned>(hop_end - h0 < 32768 ? hop_end - h0 : 32768);
+    const dim3 grid(bx, nh);
+    float *o = out + (h0 - hop_begin) * per_hop;
+    const long long f0 = static_cast<long long>(blk_frame0);
+    const unsigned long long nf = n_frames, hb = h0;
+    if (reinterpret_cast<uintptr_t>(o) & 15u) {
+      hipLaunchKernelGGL((k_overlap_add<0, false>), grid, dim3(256), 0, s, blocks, f0, nf, ch, hb, o);
+      continue;
+    }
+    switch (ch) {
+      case 1: hipLaunchKernelGGL((k_overlap_add<1, true>), grid, dim3(256), 0, s, blocks, f0, nf, ch, hb, o); break;
+      case 2: hipLaunchKernelGGL((k_overlap_add<2, true>), grid, dim3(256), 0, s, blocks, f0, nf, ch, hb, o); break;
+      case 4: hipLaunchKernelGGL((k_overlap_add<4, true>), grid, dim3(256), 0, s, blocks, f0, nf, ch, hb, o); break;
+      case 8: hipLaunchKernelGGL((k_overlap_add<8, true>), grid, dim3(256), 0, s, blocks, f0, nf, ch, hb, o); break;
+      default: hipLaunchKernelGGL((k_overlap_add<0, true>), grid, dim3(256), 0, s, blocks, f0, nf, ch, hb, o); break;
+    }
+  }
   return hipGetLastError();
 }
 
