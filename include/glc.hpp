@@ -6,6 +6,7 @@
 // glc::Error(GLC_EINVAL).  All arithmetic happens in libglc_hip.so on a gfx950 device.
 #pragma once
 #include <cstdint>
+#include <exception>
 #include <functional>
 #include <stdexcept>
 #include <string>
@@ -121,6 +122,65 @@ class EncodedAudio {
   }
   const glc_frames *handle() const { return h_; }
 
+  // ---- the structured bridge (glc.h glc_frames_view / glc_frames_gather): EncodedAudio.frames as nested
+  // vectors in one pass over the flat pools, and back by one pointer per vector - no byte stream
+  static EncodedFrame frame_from_view(const glc_frames_view &v, uint64_t f) {
+    EncodedFrame out;
+    const uint64_t l0 = v.list_begin[f], l1 = v.list_begin[f + 1];
+    out.sparse_coeffs_per_channel.resize(l1 - l0);
+    for (uint64_t l = l0; l < l1; ++l) {
+      auto &dst = out.sparse_coeffs_per_channel[l - l0];
+      const uint64_t a = v.list_off[l], b = v.list_off[l + 1];
+      dst.reserve(b - a);
+      for (uint64_t j = a; j < b; ++j) dst.emplace_back(static_cast<uint16_t>(v.pairs[j] & 0xFFFFu), static_cast<int16_t>(v.pairs[j] >> 16));
+    }
+    if (v.scale_begin[f + 1] > v.scale_begin[f]) out.scale_factors.assign(v.scales + v.scale_begin[f], v.scales + v.scale_begin[f + 1]);
+    out.has_raw_pcm = v.raw_tag[f] != 0;
+    if (out.has_raw_pcm && v.raw_begin[f + 1] > v.raw_begin[f]) out.raw_pcm.assign(v.raw + v.raw_begin[f], v.raw + v.raw_begin[f + 1]);
+    return out;
+  }
+  std::vector<EncodedFrame> frames() const {  // EncodedAudio.frames, src/codec.rs:35
+    glc_frames_view v;
+    detail::check(glc_frames_get_view(h_, &v));
+    std::vector<EncodedFrame> out;
+    out.reserve(v.n_frames);
+    for (uint64_t f = 0; f < v.n_frames; ++f) out.push_back(frame_from_view(v, f));
+    return out;
+  }
+  // EncodedAudio { header, frames, gapless_info } from the host's own nested vectors.  `stream_id`: 0, or the
+  // caller's identity (< 2^63) of this stream's content - a Decoder that still holds it decodes it again
+  // without uploading anything (glc.h glc_frames_from_parts).
+  static EncodedAudio from_frames(const AudioHeader &h, const std::vector<EncodedFrame> &frames, const GaplessInfo &g,
+                                  uint64_t stream_id = 0) {
+    static_assert(sizeof(std::pair<uint16_t, int16_t>) == 4, "(u16, i16) pairs are the library's packed pairs");
+    static const int16_t none[1] = {0};
+    const size_t nf = frames.size();
+    std::vector<uint32_t> lists_per(nf), list_len, scales_per(nf);
+    std::vector<const void *> list_ptr;
+    std::vector<const float *> scale_ptr(nf);
+    std::vector<const int16_t *> raw_ptr(nf);
+    std::vector<uint64_t> raw_len(nf);
+    for (size_t f = 0; f < nf; ++f) {
+      const EncodedFrame &fr = frames[f];
+      lists_per[f] = static_cast<uint32_t>(fr.sparse_coeffs_per_channel.size());
+      for (const auto &l : fr.sparse_coeffs_per_channel) list_ptr.push_back(l.data()), list_len.push_back(static_cast<uint32_t>(l.size()));
+      scales_per[f] = static_cast<uint32_t>(fr.scale_factors.size());
+      scale_ptr[f] = fr.scale_factors.data();
+      raw_ptr[f] = fr.has_raw_pcm ? (fr.raw_pcm.empty() ? none : fr.raw_pcm.data()) : nullptr;
+      raw_len[f] = fr.has_raw_pcm ? fr.raw_pcm.size() : 0;
+    }
+    glc_frames_gather gg{};
+    gg.sample_rate = h.sample_rate, gg.channels = h.channels, gg.total_samples = h.total_samples;
+    gg.encoder_delay = g.encoder_delay, gg.padding = g.padding, gg.original_length = g.original_length;
+    gg.n_frames = nf;
+    gg.lists_per_frame = lists_per.data(), gg.list_ptr = list_ptr.data(), gg.list_len = list_len.data();
+    gg.scales_per_frame = scales_per.data(), gg.scale_ptr = scale_ptr.data(), gg.raw_ptr = raw_ptr.data(), gg.raw_len = raw_len.data();
+    glc_frames *out = nullptr;
+    detail::check(glc_frames_from_gather(&gg, stream_id, &out));
+    return EncodedAudio(out);
+  }
+  uint64_t stream_id() const { return glc_frames_stream_id(h_); }
+
  private:
   glc_info info() const {
     glc_info i{};
@@ -145,6 +205,34 @@ class Encoder {
   }
   EncodedAudio encode(const std::vector<float> &samples, uint16_t channels) {
     return encode(samples.data(), samples.size(), channels);
+  }
+  // The same call handing the frames out as they arrive on the host, while the device still works on later
+  // ones (glc_encode_hooked): `on_frames(first_frame, frames)` is called on this thread with ascending,
+  // contiguous ranges - where an application fills its own Vec<EncodedFrame> under the encode instead of after it.
+  EncodedAudio encode(const float *samples, uint64_t n_samples, uint16_t channels,
+                      const std::function<void(uint64_t, std::vector<EncodedFrame> &&)> &on_frames) {
+    struct Ctx {
+      const std::function<void(uint64_t, std::vector<EncodedFrame> &&)> *fn;
+      std::exception_ptr error;
+    } c{&on_frames, nullptr};
+    auto tramp = [](void *user, const glc_frames_view *v, uint64_t f0, uint64_t f1) -> int {
+      Ctx &cx = *static_cast<Ctx *>(user);
+      try {  // no exception may cross the C frames of the library
+        std::vector<EncodedFrame> part;
+        part.reserve(f1 - f0);
+        for (uint64_t f = f0; f < f1; ++f) part.push_back(EncodedAudio::frame_from_view(*v, f));
+        (*cx.fn)(f0, std::move(part));
+        return 0;
+      } catch (...) {
+        cx.error = std::current_exception();
+        return 1;
+      }
+    };
+    glc_frames *h = nullptr;
+    const int rc = glc_encode_hooked(ctx_, samples, n_samples, channels, tramp, &c, &h);
+    if (c.error) std::rethrow_exception(c.error);
+    detail::check(rc, ctx_);
+    return EncodedAudio(h);
   }
   // One shard of an encode on device-resident PCM (multi-GPU hosts): frames [frame_begin, frame_end)
   // from the PCM slice [t0, t0 + t_count) per channel, fixed-size records to d_records
@@ -182,6 +270,16 @@ class Decoder {
     std::vector<float> out(glc_decoded_len(encoded.handle()));
     uint64_t n = 0;
     detail::check(glc_decode(ctx_, encoded.handle(), out.data(), out.size(), &n), ctx_);
+    out.resize(n);
+    return out;
+  }
+  // The stream whose sparse rows this Decoder still holds on the device (0: none), and its decode without
+  // an EncodedAudio (glc.h glc_decode_resident): for callers that recognise a stream by the id they gave it
+  uint64_t resident_stream() const { return glc_ctx_resident_stream(ctx_); }
+  std::vector<float> decode_resident(uint64_t stream_id, uint64_t decoded_len) {
+    std::vector<float> out(decoded_len);
+    uint64_t n = 0;
+    detail::check(glc_decode_resident(ctx_, stream_id, out.data(), out.size(), &n), ctx_);
     out.resize(n);
     return out;
   }

@@ -56,6 +56,45 @@ int main(int argc, char **argv) {
       raw_frames += fr.has_raw_pcm;
       for (const auto &l : fr.sparse_coeffs_per_channel) nnz += l.size();
     }
+    // the structured bridge through the C++ mirror: frames() == frame(f) for every f; the nested vectors go
+    // back in by pointer (from_frames) and serialise to the same bytes; the hooked encode hands out the same
+    // frames in ascending contiguous ranges; a stream id makes the second decode a resident one
+    {
+      const std::vector<glc::EncodedFrame> all = loaded.frames();
+      if (all.size() != loaded.n_frames()) return std::fprintf(stderr, "frames(): wrong count\n"), 1;
+      for (uint64_t f = 0; f < loaded.n_frames(); ++f) {
+        const glc::EncodedFrame one = loaded.frame(f);
+        if (one.sparse_coeffs_per_channel != all[f].sparse_coeffs_per_channel || one.scale_factors != all[f].scale_factors ||
+            one.has_raw_pcm != all[f].has_raw_pcm || one.raw_pcm != all[f].raw_pcm)
+          return std::fprintf(stderr, "frames() differs from frame(%llu)\n", (unsigned long long)f), 1;
+      }
+      const glc::EncodedAudio again = glc::EncodedAudio::from_frames(loaded.header(), all, loaded.gapless_info(), 4711);
+      if (again.to_bytes() != loaded.to_bytes() || again.stream_id() != 4711) return std::fprintf(stderr, "from_frames: bytes differ\n"), 1;
+      std::vector<glc::EncodedFrame> hooked;
+      uint64_t next = 0;
+      bool ordered = true;
+      const glc::EncodedAudio e2 = encoder.encode(pcm.data(), pcm.size(), ch, [&](uint64_t f0, std::vector<glc::EncodedFrame> &&part) {
+        ordered = ordered && f0 == next;
+        next = f0 + part.size();
+        for (auto &fr : part) hooked.push_back(std::move(fr));
+      });
+      if (!ordered || hooked.size() != all.size() || e2.to_bytes() != loaded.to_bytes())
+        return std::fprintf(stderr, "hooked encode: ranges or bytes differ\n"), 1;
+      for (size_t f = 0; f < all.size(); ++f)
+        if (hooked[f].sparse_coeffs_per_channel != all[f].sparse_coeffs_per_channel || hooked[f].scale_factors != all[f].scale_factors ||
+            hooked[f].raw_pcm != all[f].raw_pcm)
+          return std::fprintf(stderr, "hooked encode: frame %zu differs\n", f), 1;
+      glc::Decoder d2(ch, sr);
+      const std::vector<float> first = d2.decode(again);
+      if (d2.resident_stream() != 4711) return std::fprintf(stderr, "stream id not resident\n"), 1;
+      const std::vector<float> second = d2.decode_resident(4711, first.size());
+      if (first != whole || second != whole) return std::fprintf(stderr, "bridge decodes differ\n"), 1;
+      try {
+        encoder.encode(pcm.data(), pcm.size(), ch, [](uint64_t, std::vector<glc::EncodedFrame> &&) { throw std::runtime_error("stop"); });
+        return std::fprintf(stderr, "a throwing hook was swallowed\n"), 1;
+      } catch (const std::runtime_error &) {
+      }
+    }
     // src/audio.rs + src/flac.rs twins through the C++ mirror: export the decoded samples to FLAC and
     // WAV next to the output file and read both back (tests/test_export.rs)
     const std::string flac_path = std::string(argv[5]) + ".flac", wav_path = std::string(argv[5]) + ".wav";
