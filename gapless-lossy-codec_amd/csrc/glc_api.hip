@@ -163,6 +163,7 @@ struct glc_ctx {
   uint32_t dec_delay = 0;
   uint64_t dec_orig_len = 0, dec_n_pairs = 0, dec_n_raw = 0;
   int d1_variant = 0;    // include/glc_debug.h: which inverse-transform kernel / path to launch
+  int k1_variant = 0;    // include/glc_debug.h: which forward-transform kernel takes launches of >= 4096 rows
   hipStream_t probe_stream = nullptr;  // include/glc_debug.h clock probe
   HostBuf probe_out;
   uint32_t dec_ch = 0;
@@ -472,7 +473,7 @@ static int encode_range_on(glc_ctx *ctx, hipStream_t stream, DevBuf &coef_ws, co
     hipStream_t st = odd ? ctx->stream_b : stream;
     float *coef = d_coeffs ? d_coeffs + (f - frame_begin) * ch * glc::kHop : static_cast<float *>(odd ? ctx->coef_b.p : coef_ws.p);
     uint8_t *r = recs + (f - frame_begin) * rec;
-    GLC_HIP(ctx, glc::launch_mdct_forward(ctx->dev, view, f, M, coef, st));
+    GLC_HIP(ctx, glc::launch_mdct_forward(ctx->dev, view, f, M, coef, st, ctx->k1_variant));
     bool decided = false;
     GLC_HIP(ctx, glc::launch_quantize(ctx->dev, coef, M, ch, view, f, r, st, &decided));
     if (!decided) GLC_HIP(ctx, glc::launch_decide_raw(ctx->dev, view, f, static_cast<uint32_t>(nf), r, st));
@@ -504,7 +505,7 @@ int glc_mdct_forward_device(glc_ctx *ctx, const float *d_pcm, uint64_t t0, uint6
   DeviceGuard guard(ctx->device);
   glc::PcmView view{d_pcm, t0, t_count, n_samples, channels};
   GLC_HIP(ctx, glc::launch_mdct_forward(ctx->dev, view, frame_begin, static_cast<uint32_t>(rows), d_coeffs,
-                                        ctx->stream));
+                                        ctx->stream, ctx->k1_variant));
   return GLC_OK;
 }
 
@@ -1393,6 +1394,12 @@ int glc_debug_set_imdct_variant(glc_ctx *ctx, int variant) {
   if (!ctx || variant < 0 || variant > 6) return fail(ctx, GLC_EINVAL, "glc_debug_set_imdct_variant: variant must be 0..6");
   if (variant != ctx->d1_variant) ctx->plan_uid = 0;  // variants 5 / 6 deal the units differently: the kept order is not theirs
   ctx->d1_variant = variant;
+  return GLC_OK;
+}
+
+int glc_debug_set_mdct_variant(glc_ctx *ctx, int variant) {
+  if (!ctx || variant < 0 || variant > 3) return fail(ctx, GLC_EINVAL, "glc_debug_set_mdct_variant: variant must be 0..3");
+  ctx->k1_variant = variant;
   return GLC_OK;
 }
 

@@ -1001,16 +1001,46 @@ namespace {
 
 // ---------------------------------------------------------------------------- launchers
 
-constexpr int kK1Prio = 1;  // glc_mdct_fwd.hpp PRIO: priority by quarter of the i loop (k1_tune: 0.560 against 0.572-0.605 ms at config 2)
+// Which kernel takes a launch of 4096 rows or more (the rest of the dispatch is by row count alone):
+//   st 16 waves  256 x 128 tiles, one 1024-thread workgroup per CU: a launch runs in rounds of 256 tiles;
+//   st 8 waves   256 x 64 tiles, two 512-thread workgroups per CU: rounds of 512, and a CU with one
+//                workgroup left finishes it in about 0.6 of a round.
+// The 16-wave form is 2 % faster on full rounds (its staging and barrier cost nothing: k1_tune [abl]) and
+// worse on a last round that is half empty - so it takes the launches whose last round of 32 row tiles is
+// full or more than half full, the 8-wave form the rest (profiles/r03_k1_tune_st_*.txt).
+namespace {
+template <int NW>
+hipError_t launch_st_ch(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M, float *coef,
+                        hipStream_t s) {
+  // PCM by one dwordx4 per lane and piece when the channel count divides the tile height, else one
+  // dword per (row, sample).  PRIO: 8 waves - by quarter of the i loop (between a CU's two workgroups);
+  // 16 waves - by distance from the last barrier (inside the workgroup).
+  constexpr int P = NW == 8 ? 1 : 2;
+  switch (pcm.ch) {
+    case 1: return k1::launch_st<4, 1, P, 4, NW>(t, pcm, frame_begin, M, coef, s);
+    case 2: return k1::launch_st<4, 2, P, 4, NW>(t, pcm, frame_begin, M, coef, s);
+    case 4: return k1::launch_st<4, 4, P, 4, NW>(t, pcm, frame_begin, M, coef, s);
+    case 8: return k1::launch_st<4, 8, P, 4, NW>(t, pcm, frame_begin, M, coef, s);
+    default: return k1::launch_st<4, 0, P, 4, NW>(t, pcm, frame_begin, M, coef, s);
+  }
+}
+hipError_t launch_dma_ch(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M, float *coef,
+                         hipStream_t s) {
+  switch (pcm.ch) {
+    case 1: return k1::launch_dma<4, 1, 1>(t, pcm, frame_begin, M, coef, s);
+    case 2: return k1::launch_dma<4, 2, 1>(t, pcm, frame_begin, M, coef, s);
+    case 4: return k1::launch_dma<4, 4, 1>(t, pcm, frame_begin, M, coef, s);
+    case 8: return k1::launch_dma<4, 8, 1>(t, pcm, frame_begin, M, coef, s);
+    default: return k1::launch_dma<4, 0, 1>(t, pcm, frame_begin, M, coef, s);
+  }
+}
+}  // namespace
 
 hipError_t launch_mdct_forward(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin,
-                               uint32_t M, float *coef, hipStream_t s) {
-  // Shapes measured with tools/k1_tune.hip (profiles/r01_k1_tune_*.txt).  The f32 VALU needs
-  // >= 4 waves per SIMD to approach its issue rate, so batches that give fewer than ~8
-  // 128x128 tiles per CU use 4x8 outputs per lane (32 accumulators, 93 VGPRs) in 512-thread
-  // workgroups: 2 workgroups = 16 waves per CU at BASELINE config 2, table tile by LDS-DMA.
-  // The 8x8-per-lane register-staged kernel measures the same at M >= 16384 (k1_tune), so one
-  // kernel serves every batch of 4096 rows or more; short clips use 64-row tiles.
+                               uint32_t M, float *coef, hipStream_t s, int variant) {
+  // Shapes measured with tools/k1_tune.hip.  The f32 VALU needs >= 4 waves per SIMD to approach its
+  // issue rate, so every kernel for 4096 rows or more keeps 4 x 8 outputs per lane (32 accumulators) and
+  // 16 waves per CU.
   // A clip of a few seconds is latency-bound by one wave's chain of 2048 dependent i-steps, not by
   // throughput, and the length of a step is the lane tile: cut it until every SIMD has a wave of its own
   // (glc_mdct_fwd.hpp k_mdct_fwd_small: 2 x 2 outputs per lane, then 2 x 4).  Measured against the 4 x 8
@@ -1019,15 +1049,13 @@ hipError_t launch_mdct_forward(const DeviceTables &t, const PcmView &pcm, uint64
   if (M <= 640) return k1::launch_small<2>(t, pcm, frame_begin, M, coef, s);
   if (M <= 1792) return k1::launch_small<4>(t, pcm, frame_begin, M, coef, s);
   if (M < 4096) return k1::launch_sched<64, 128, 16, 4>(t, pcm, frame_begin, M, coef, s);  // 1793..4095 rows: more workgroups than the 128-row tile gives
-  // 512 threads, 4x8 per lane, table tile by LDS-DMA; PCM by one dwordx4 per lane and stage when the
-  // channel count divides the tile height, else one dword per (row, sample)
-  switch (pcm.ch) {
-    case 1: return k1::launch_dma<4, 1, kK1Prio>(t, pcm, frame_begin, M, coef, s);
-    case 2: return k1::launch_dma<4, 2, kK1Prio>(t, pcm, frame_begin, M, coef, s);
-    case 4: return k1::launch_dma<4, 4, kK1Prio>(t, pcm, frame_begin, M, coef, s);
-    case 8: return k1::launch_dma<4, 8, kK1Prio>(t, pcm, frame_begin, M, coef, s);
-    default: return k1::launch_dma<4, 0, kK1Prio>(t, pcm, frame_begin, M, coef, s);
-  }
+  // variant (include/glc_debug.h glc_debug_set_mdct_variant): 0 = shipped, 1 = round 3's kernel, 2 / 3 = one form for every launch
+  if (variant == 1) return launch_dma_ch(t, pcm, frame_begin, M, coef, s);
+  if (variant == 2) return launch_st_ch<8>(t, pcm, frame_begin, M, coef, s);
+  if (variant == 3) return launch_st_ch<16>(t, pcm, frame_begin, M, coef, s);
+  const unsigned last_round = ((M + 255) / 256) % 32;  // row tiles in the last round of 32
+  if (last_round == 0 || last_round > 16) return launch_st_ch<16>(t, pcm, frame_begin, M, coef, s);
+  return launch_st_ch<8>(t, pcm, frame_begin, M, coef, s);
 }
 
 hipError_t launch_quantize(const DeviceTables &t, const float *coef, uint32_t M, uint32_t ch, const PcmView &pcm,

@@ -776,6 +776,366 @@ inline hipError_t launch_dma(const DeviceTables &t, const PcmView &pcm, uint64_t
 
 
 // ------------------------------------------------------------------------------------------
+// Scalar-table kernel (256 x 64 tile, 512 threads, 4 rows x 8 columns per lane, lanes <-> ROWS).
+// The other kernels give a lane its own columns, so the table value is the per-lane operand and the
+// sample the shared one - and a shared operand that is windowed on the fly cannot come from anywhere
+// but LDS.  Turn the tile round: the 64 lanes of a wave hold 256 DIFFERENT rows and the SAME 8 columns.
+// The 8 table values of an i-step are then wave-uniform and static - one s_load_dwordx8 straight from
+// the table in global memory into SGPRs, no table tile in LDS at all - and the lane's 4 windowed samples
+// are one ds_read_b128.  Per i-step and wave: 1 KiB out of LDS instead of 3 KiB, one operand of every
+// v_pk_mul from the scalar file (tools/microbench_sgpr.hip: the same stream holds 3-5 % more clock
+// that way).  Same products, same ascending-i adds, one accumulator per output.
+// Scalar loads return out of order, so every wait is lgkmcnt(0); operands are therefore fetched TWO
+// i-steps at a time, a whole pair ahead (as k_imdct_apply does with its records).
+// ------------------------------------------------------------------------------------------
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+
+template <int D>
+struct StOps {  // operands of D i-steps: 4 rows of this lane (VGPRs), 8 columns of this wave (SGPRs)
+  f32x4 a[D];
+  u32x8 b[D];
+};
+
+// II: i-step inside the stage (compile time: all offsets are immediates)
+template <int II>
+__device__ __forceinline__ void st_fetch_b(u32x8 &b, const unsigned *brow) {
+  asm volatile("s_load_dwordx8 %0, %1, %c2" : "=&s"(b) : "s"(brow), "i"(II * kHopI * 4) : "memory");
+}
+template <int II, int AS>
+__device__ __forceinline__ void st_fetch_a(f32x4 &a, unsigned a_addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=&v"(a) : "v"(a_addr), "i"(II * AS * 4) : "memory");
+}
+template <int II, int AS, int D>
+__device__ __forceinline__ void st_fetch(StOps<D> &o, unsigned a_addr, const unsigned *brow) {
+  static_assert(D == 2 || D == 4, "i-steps per fetch");
+  st_fetch_b<II>(o.b[0], brow);
+  st_fetch_b<II + 1>(o.b[1], brow);
+  if constexpr (D == 4) {
+    st_fetch_b<II + 2>(o.b[2], brow);
+    st_fetch_b<II + 3>(o.b[3], brow);
+  }
+  st_fetch_a<II, AS>(o.a[0], a_addr);
+  st_fetch_a<II + 1, AS>(o.a[1], a_addr);
+  if constexpr (D == 4) {
+    st_fetch_a<II + 2, AS>(o.a[2], a_addr);
+    st_fetch_a<II + 3, AS>(o.a[3], a_addr);
+  }
+}
+
+// scalar and vector results are tied in SEPARATE statements (an asm with one VGPR output makes all of
+// its outputs divergent to LLVM, and the table values would be copied to VGPRs)
+template <int D>
+__device__ __forceinline__ void st_wait(StOps<D> &o) {
+  if constexpr (D == 2) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(o.b[0]), "+s"(o.b[1])::"memory");
+    asm volatile("" : "+v"(o.a[0]), "+v"(o.a[1])::"memory");
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(o.b[0]), "+s"(o.b[1]), "+s"(o.b[2]), "+s"(o.b[3])::"memory");
+    asm volatile("" : "+v"(o.a[0]), "+v"(o.a[1]), "+v"(o.a[2]), "+v"(o.a[3])::"memory");
+  }
+}
+
+// rows (r, r+1) x 8 columns, table pairs in SGPRs: the instruction block of mac2rows
+__device__ __forceinline__ void mac2rows_st(f32x2 (&c0)[4], f32x2 (&c1)[4], f32x2 a, u32x2 b0, u32x2 b1, u32x2 b2,
+                                            u32x2 b3) {
+  f32x2 t0, t1, t2, t3, t4, t5, t6, t7;
+  asm volatile(
+      "v_pk_mul_f32 %8, %16, %17 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %9, %16, %18 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %10, %16, %19 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %11, %16, %20 op_sel_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %12, %16, %17 op_sel:[1,0]\n\t"
+      "v_pk_mul_f32 %13, %16, %18 op_sel:[1,0]\n\t"
+      "v_pk_mul_f32 %14, %16, %19 op_sel:[1,0]\n\t"
+      "v_pk_mul_f32 %15, %16, %20 op_sel:[1,0]\n\t"
+      "v_pk_add_f32 %0, %0, %8\n\t"
+      "v_pk_add_f32 %1, %1, %9\n\t"
+      "v_pk_add_f32 %2, %2, %10\n\t"
+      "v_pk_add_f32 %3, %3, %11\n\t"
+      "v_pk_add_f32 %4, %4, %12\n\t"
+      "v_pk_add_f32 %5, %5, %13\n\t"
+      "v_pk_add_f32 %6, %6, %14\n\t"
+      "v_pk_add_f32 %7, %7, %15"
+      : "+v"(c0[0]), "+v"(c0[1]), "+v"(c0[2]), "+v"(c0[3]), "+v"(c1[0]), "+v"(c1[1]), "+v"(c1[2]), "+v"(c1[3]),
+        "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+      : "v"(a), "s"(b0), "s"(b1), "s"(b2), "s"(b3));
+}
+
+// the fetch's i-steps: ascending i, for every output
+template <int D>
+__device__ __forceinline__ void st_mac(f32x2 (&acc)[4][4], const StOps<D> &o) {
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    mac2rows_st(acc[0], acc[1], o.a[d].xy, o.b[d].s01, o.b[d].s23, o.b[d].s45, o.b[d].s67);
+    mac2rows_st(acc[2], acc[3], o.a[d].zw, o.b[d].s01, o.b[d].s23, o.b[d].s45, o.b[d].s67);
+  }
+}
+
+// NW waves per workgroup (8: 256 x 64 tile, two workgroups per CU;  16: 256 x 128, one), BK i-steps per
+// LDS stage, D i-steps per operand fetch.
+// PRIO 1: priority by quarter of the i loop (between the two workgroups of a CU, as k_mdct_fwd_dma);
+// PRIO 2: by distance from the last barrier (inside a workgroup: whoever is behind goes first).
+// ABL (tuning only, wrong results): 1 = the table address does not advance, 2 = no staging and no barrier.
+template <int MINW, int CH = 0, int PRIO = 0, int D = 2, int NW = 8, int BK = 16, int ABL = 0>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
+void k_mdct_fwd_st(DeviceTables tb, PcmView pcm, long long frame_begin, unsigned M, float *__restrict__ coef) {
+  // CH as in k_mdct_fwd_dma: 0 = one PCM dword per (row, i) and lane; 1 / 2 / 4 / 8 = the stream's
+  // channel count, BK samples x CH channels of a frame fetched as BK / 4 * CH dwordx4.
+  constexpr int BM = 256, BN = 8 * NW, RING = 3;
+  constexpr int kAS = BM + 4;  // the same bank spread as GLC_K1_A_STRIDE (260 = 132 = 4 mod 64)
+  constexpr int kThreads = NW * 64;
+  constexpr int kNTiles = kHopI / BN;
+  constexpr bool kSeg = CH != 0;
+  static_assert(!kSeg || CH == 1 || CH == 2 || CH == 4 || CH == 8, "segment loader shapes");
+  static_assert((BK == 16 || BK == 32) && BK % (2 * D) == 0, "stage depth");
+  constexpr int kIGroups = kThreads / BM;          // per-row loader: i = a_i + kIGroups * j
+  constexpr int kAPer = BK / kIGroups;             //   dwords per lane and stage
+  constexpr int kPieces = BM * BK / 4 / kThreads;  // segment loader: dwordx4 per lane and stage
+  static_assert(kAPer == 4 || kAPer == 8, "per-row loader shapes");
+  static_assert(kPieces == 1 || kPieces == 2, "segment loader shapes");
+  __shared__ __attribute__((aligned(16))) float As[RING][BK * kAS];
+  __shared__ __attribute__((aligned(16))) float Ws[kFrameI];
+
+  const int tid = threadIdx.x;
+  const unsigned g = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // XCD-aware tile map
+  const int n_tile = g % kNTiles;
+  const int m_tile = g / kNTiles;
+  const int m0 = m_tile * BM;
+  const int n0 = n_tile * BN;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+
+  for (int i = tid; i < kFrameI; i += kThreads) Ws[i] = tb.window[i];
+
+  const long long ch = pcm.ch;
+  const long long f0 = frame_begin + m0 / pcm.ch;
+  const long long e_first = (f0 * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * ch;
+  long long e_end = static_cast<long long>(pcm.t_count) * ch;
+  const long long n_rel = static_cast<long long>(pcm.n_samples) - static_cast<long long>(pcm.t0) * ch;
+  if (e_end > n_rel) e_end = n_rel;
+  const long long e_base = e_first < 0 ? 0 : e_first;
+  long long e_cnt = e_end - e_base;
+  if (e_cnt < 0) e_cnt = 0;
+  if (e_cnt > (1ll << 28)) e_cnt = 1ll << 28;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(pcm.p + e_base), 0, static_cast<int>(e_cnt * 4), 0x00020000);
+
+  // per-row loader: lane -> (row a_r of the tile, i = a_i + kIGroups * j)
+  const int a_r = tid % BM;
+  const int a_i = tid / BM;
+  unsigned a_off[2] = {0x80000000u, 0x80000000u};
+  const unsigned a_step = static_cast<unsigned>(kIGroups * ch * 4);
+  const unsigned i_bytes = static_cast<unsigned>(ch * 4);
+  // segment loader: (lane, p) -> (frame seg_fl + p * kSegHalf of the tile, 4 consecutive floats of its BK x CH segment)
+  constexpr int kSegCh = kSeg ? CH : 1;
+  constexpr int kSegLanes = BK / 4 * kSegCh;  // lanes per frame segment
+  constexpr int kSegHalf = kThreads / kSegLanes;
+  const int seg_fl = tid / kSegLanes;
+  const int seg_o = (tid % kSegLanes) * 4;
+  if constexpr (kSeg) {
+#pragma unroll
+    for (int p = 0; p < kPieces; ++p) {
+      const unsigned row0 = m0 + (seg_fl + p * kSegHalf) * CH;
+      if (row0 < M) {
+        const long long f = frame_begin + row0 / CH;
+        const long long e_row = (f * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * CH;
+        a_off[p] = static_cast<unsigned>((e_row - e_base + seg_o) * 4);
+      }
+    }
+  } else {
+    const unsigned a_row = m0 + a_r;
+    if (a_row < M) {
+      const long long f = frame_begin + a_row / pcm.ch;
+      const long long c = a_row % pcm.ch;
+      const long long e_row = (f * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * ch + c;
+      a_off[0] = static_cast<unsigned>((e_row - e_base + a_i * ch) * 4);
+    }
+  }
+
+  float a_raw[8];
+  f32x4 a_seg[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  auto issue_a = [&](int i0) {  // asm: hipcc must not count these loads (see lds_fetch4)
+    if constexpr (kSeg) {
+      const unsigned o0 = a_off[0] + static_cast<unsigned>(i0) * i_bytes;
+      if constexpr (kPieces == 1) {
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(a_seg[0]) : "v"(o0), "s"(a_rsrc) : "memory");
+      } else {
+        const unsigned o1 = a_off[1] + static_cast<unsigned>(i0) * i_bytes;
+        asm volatile("buffer_load_dwordx4 %0, %2, %4, 0 offen\n\tbuffer_load_dwordx4 %1, %3, %4, 0 offen"
+                     : "=&v"(a_seg[0]), "=&v"(a_seg[1])
+                     : "v"(o0), "v"(o1), "s"(a_rsrc)
+                     : "memory");
+      }
+      return;
+    }
+    const unsigned o = a_off[0] + static_cast<unsigned>(i0) * i_bytes;
+    asm volatile(
+        "buffer_load_dword %0, %4, %8, 0 offen\n\t"
+        "buffer_load_dword %1, %5, %8, 0 offen\n\t"
+        "buffer_load_dword %2, %6, %8, 0 offen\n\t"
+        "buffer_load_dword %3, %7, %8, 0 offen"
+        : "=&v"(a_raw[0]), "=&v"(a_raw[1]), "=&v"(a_raw[2]), "=&v"(a_raw[3])
+        : "v"(o), "v"(o + a_step), "v"(o + 2 * a_step), "v"(o + 3 * a_step), "s"(a_rsrc)
+        : "memory");
+    if constexpr (kAPer == 8)
+      asm volatile(
+          "buffer_load_dword %0, %4, %8, 0 offen\n\t"
+          "buffer_load_dword %1, %5, %8, 0 offen\n\t"
+          "buffer_load_dword %2, %6, %8, 0 offen\n\t"
+          "buffer_load_dword %3, %7, %8, 0 offen"
+          : "=&v"(a_raw[4]), "=&v"(a_raw[5]), "=&v"(a_raw[6]), "=&v"(a_raw[7])
+          : "v"(o + 4 * a_step), "v"(o + 5 * a_step), "v"(o + 6 * a_step), "v"(o + 7 * a_step), "s"(a_rsrc)
+          : "memory");
+  };
+  auto store_a = [&](int i0, int slot) {
+    if constexpr (kSeg) {
+#pragma unroll
+      for (int p = 0; p < kPieces; ++p)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = seg_o + j;  // float e of the segment: sample i = e / CH of channel e % CH
+          const int ii = e / CH;
+          As[slot][ii * kAS + (seg_fl + p * kSegHalf) * CH + e % CH] = mul_rn(a_seg[p][j], Ws[i0 + ii]);  // :480
+        }
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < kAPer; ++j) {
+      const int ii = a_i + kIGroups * j;
+      As[slot][ii * kAS + a_r] = mul_rn(a_raw[j], Ws[i0 + ii]);  // block[i] = slice[i]*window[i], :480
+    }
+  };
+  auto wait_staged = [&]() {
+    if constexpr (kSeg)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(a_seg[0]), "+v"(a_seg[1])::"memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(a_raw[0]), "+v"(a_raw[1]), "+v"(a_raw[2]), "+v"(a_raw[3]), "+v"(a_raw[4]), "+v"(a_raw[5]),
+                     "+v"(a_raw[6]), "+v"(a_raw[7])::"memory");
+  };
+
+  f32x2 acc[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = f32x2{0.0f, 0.0f};
+
+  constexpr int kStages = kFrameI / BK;
+  // prologue: stage 0 complete in slot 0, PCM of stage 1 in registers
+  __syncthreads();  // Ws
+  issue_a(0);
+  wait_staged();
+  store_a(0, 0);
+  issue_a(BK);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const unsigned a_lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(&As[0][lane * 4]));
+  // this wave's 8 columns of table row 0 (wave-uniform: the scalar loads' base)
+  const unsigned *b_base = reinterpret_cast<const unsigned *>(tb.cos_t) + n0 + 8 * wave;
+
+  // Stage hand-off in the middle of a stage, as in k_mdct_fwd_dma: the samples of stage s+1 are
+  // published by a barrier after the first BK / 2 i-steps, the stage's last fetch takes the first operands
+  // of stage s+1, and the PCM loads of stage s+2 are issued behind the barrier.  Slot use: stage s reads
+  // slot s % 3; As[(s+1) % 3] is written before the barrier of stage s (last read in stage s-2).
+  StOps<D> X, Y;
+  st_fetch<0, kAS>(X, a_lds0, b_base);
+  st_wait(X);
+  if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(3);
+#pragma unroll 1
+  for (int s = 0; s < kStages; ++s) {
+    if constexpr (PRIO == 1) {
+      constexpr int kQuarter = kStages / 4;
+      if (s % kQuarter == 0) {
+        const int level = (s / kQuarter) & 3;
+        if (level == 0) __builtin_amdgcn_s_setprio(3);
+        else if (level == 1) __builtin_amdgcn_s_setprio(2);
+        else if (level == 2) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+      }
+    }
+    if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(0);  // half-way between two barriers
+    const int slot = (ABL & 2) ? 0 : s % 3, nslot = (ABL & 2) ? 0 : (s + 1) % 3;
+    const unsigned a_addr = a_lds0 + slot * (BK * kAS * 4);
+    const unsigned a_next = a_lds0 + nslot * (BK * kAS * 4);
+    const unsigned *brow = (ABL & 1) ? b_base : b_base + static_cast<size_t>(s) * (BK * kHopI);
+    const unsigned *brow_next = (ABL & 1) ? b_base : b_base + static_cast<size_t>((s + 1) & (kStages - 1)) * (BK * kHopI);
+    // the hand-off: PCM registers of stage s+1 (issued in the middle of stage s-1) have landed -> LDS,
+    // lgkmcnt(0) (this wave's ds_writes and the operands in flight), barrier, PCM loads of stage s+2
+#define GLC_ST_HANDOFF(NEXT)                                      \
+  do {                                                            \
+    wait_staged();                                                \
+    store_a(((s + 1) & (kStages - 1)) * BK, nslot);               \
+    st_wait(NEXT);                                                \
+    __builtin_amdgcn_s_barrier();                                 \
+    if constexpr (PRIO == 2) __builtin_amdgcn_s_setprio(1);       \
+    issue_a(((s + 2) & (kStages - 1)) * BK);                      \
+  } while (0)
+    // X holds the operands of i-steps [0, D) of the stage; groups alternate X, Y
+#define GLC_ST_GROUP(CUR, NXT, II)                                                        \
+  do {                                                                                    \
+    if constexpr ((II) + D < BK) st_fetch<((II) + D) % BK, kAS>(NXT, a_addr, brow);        \
+    else st_fetch<0, kAS>(NXT, a_next, brow_next);                                        \
+    st_mac(acc, CUR);                                                                     \
+    if constexpr ((II) + D == BK / 2 && !(ABL & 2)) GLC_ST_HANDOFF(NXT);                  \
+    else st_wait(NXT);                                                                    \
+  } while (0)
+    GLC_ST_GROUP(X, Y, 0);
+    GLC_ST_GROUP(Y, X, D);
+    if constexpr (BK / D > 2) {
+      GLC_ST_GROUP(X, Y, 2 * D);
+      GLC_ST_GROUP(Y, X, 3 * D);
+    }
+    if constexpr (BK / D > 4) {
+      GLC_ST_GROUP(X, Y, 4 * D);
+      GLC_ST_GROUP(Y, X, 5 * D);
+      GLC_ST_GROUP(X, Y, 6 * D);
+      GLC_ST_GROUP(Y, X, 7 * D);
+    }
+    if constexpr (BK / D > 8) {
+      GLC_ST_GROUP(X, Y, 8 * D);
+      GLC_ST_GROUP(Y, X, 9 * D);
+      GLC_ST_GROUP(X, Y, 10 * D);
+      GLC_ST_GROUP(Y, X, 11 * D);
+      GLC_ST_GROUP(X, Y, 12 * D);
+      GLC_ST_GROUP(Y, X, 13 * D);
+      GLC_ST_GROUP(X, Y, 14 * D);
+      GLC_ST_GROUP(Y, X, 15 * D);
+    }
+#undef GLC_ST_GROUP
+#undef GLC_ST_HANDOFF
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the wrap-around prefetch
+
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const unsigned row = m0 + lane * 4 + r;
+    if (row >= M) continue;
+    float *dst = coef + static_cast<size_t>(row) * kHopI + n0 + 8 * wave;
+    float4 o;
+    o.x = mul_rn(acc[r][0].x, tb.norm); o.y = mul_rn(acc[r][0].y, tb.norm);
+    o.z = mul_rn(acc[r][1].x, tb.norm); o.w = mul_rn(acc[r][1].y, tb.norm);
+    *reinterpret_cast<float4 *>(dst) = o;
+    o.x = mul_rn(acc[r][2].x, tb.norm); o.y = mul_rn(acc[r][2].y, tb.norm);
+    o.z = mul_rn(acc[r][3].x, tb.norm); o.w = mul_rn(acc[r][3].y, tb.norm);
+    *reinterpret_cast<float4 *>(dst + 4) = o;
+  }
+}
+
+template <int MINW, int CH = 0, int PRIO = 0, int D = 2, int NW = 8, int BK = 16, int ABL = 0>
+inline hipError_t launch_st(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M, float *coef,
+                            hipStream_t s) {
+  if (M == 0) return hipSuccess;
+  if (CH != 0 && pcm.ch != static_cast<uint32_t>(CH)) return hipErrorInvalidValue;
+  const unsigned m_tiles = (M + 255) / 256;
+  hipLaunchKernelGGL((k_mdct_fwd_st<MINW, CH, PRIO, D, NW, BK, ABL>), dim3(m_tiles * (kHopI / (8 * NW))), dim3(NW * 64), 0,
+                     s, t, pcm, static_cast<long long>(frame_begin), M, coef);
+  return hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------------------------------
 // Short clips (<= 1792 rows: BASELINE config 1 and every clip of the reference's own tests).  A launch
 // this small cannot fill the chip; what it costs is ONE wave's chain of 2048 dependent i-steps, and the
 // length of a step is the lane tile: 128 VALU cycles for 4 x 8 outputs, 16 for 2 x 2.  So the tile is

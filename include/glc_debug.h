@@ -27,6 +27,16 @@ extern "C" {
  * All of them produce the same bits; tools/soak_decode.py checks that on random streams. */
 int glc_debug_set_imdct_variant(glc_ctx *ctx, int variant);
 
+/* Which forward-transform kernel takes the launches of 4096 rows or more of `ctx` (mdct_block,
+ * src/codec.rs:359-375; shorter launches are dispatched by row count alone and are not affected):
+ *   0  shipped: k_mdct_fwd_st - table values from SGPRs, a wave's lanes hold 256 rows -, 16 waves per
+ *      workgroup when the launch's last round of 32 row tiles is full or more than half full, else 8
+ *   1  k_mdct_fwd_dma: round 3's kernel (128 x 128 tile, both operands from LDS)
+ *   2  k_mdct_fwd_st, 8 waves per workgroup for every launch
+ *   3  k_mdct_fwd_st, 16 waves per workgroup for every launch
+ * All of them produce the same bits (tests/test_gpu_parity.py). */
+int glc_debug_set_mdct_variant(glc_ctx *ctx, int variant);
+
 /* The shader clock the device HOLDS under load (measurement only; bench.py's roofline.clock_ghz_held).
  * `begin` starts one sleeping wave on a stream of its own that runs for `window_us` microseconds beside
  * whatever the caller queues meanwhile and reads the shader-cycle counter against the constant 100 MHz

@@ -727,15 +727,29 @@ def _k1_stream(ch, frames, seed):
     return x.reshape(-1)[:n], sr
 
 
+def _set_mdct_variant(ctx, v):
+    glc_amd.lib.glc_debug_set_mdct_variant.restype = C.c_int
+    glc_amd.lib.glc_debug_set_mdct_variant.argtypes = [C.c_void_p, C.c_int]
+    assert glc_amd.lib.glc_debug_set_mdct_variant(ctx._h, v) == 0
+
+
+# which kernel a launch reaches: by its row count (sched), or pinned through include/glc_debug.h (1 = dma:
+# round 3's kernel, 2 / 3 = k_mdct_fwd_st with 8 / 16 waves per workgroup); "shipped" = the dispatch itself at
+# 8192 + rows (16 waves: the last round of row tiles is full ... more than half full)
+_K1_KERNELS = {"sched": (2300, 0), "dma": (4096 + 333, 1), "st8": (4096 + 333, 2), "st16": (4096 + 333, 3),
+               "shipped": (8192 + 4400, 0)}
+
+
 @pytest.mark.parametrize("ch", [1, 2, 4, 8, 3])
-@pytest.mark.parametrize("kernel", ["sched", "dma"])
+@pytest.mark.parametrize("kernel", list(_K1_KERNELS))
 def test_k1_large_launch_coefficient_bits(torch_cuda, ch, kernel):
-    rows_wanted = 2300 if kernel == "sched" else 4096 + 333
+    rows_wanted, variant = _K1_KERNELS[kernel]
     frames = -(-rows_wanted // ch) + 3
     x, sr = _k1_stream(ch, frames, 100 + ch)
     plan = glc_amd.plan_encode(x.size, ch)
     nf, L = plan.n_frames, plan.per_channel
     enc = glc_amd.Encoder(sr)
+    _set_mdct_variant(enc, variant)
     W = 5  # frames per oracle window
 
     def launch_and_check(f0, t0, t_count, windows):
@@ -755,9 +769,20 @@ def test_k1_large_launch_coefficient_bits(torch_cuda, ch, kernel):
             got = coef[(a - f0) * ch:(b - f0) * ch]
             assert np.array_equal(bits(got), bits(ref.coeffs)), \
                 f"{kernel} ch={ch}: {(bits(got) != bits(ref.coeffs)).sum()} coefficient words differ in frames [{a},{b})"
+        if kernel != "sched":  # every row of the launch: the other kernels for this size give the same words
+            for other in (1, 2, 3):
+                if other == variant:
+                    continue
+                _set_mdct_variant(enc, other)
+                d_coef.fill_(float("nan"))
+                torch_cuda.cuda.synchronize()
+                enc.mdct_forward_device(d_pcm.data_ptr(), t0, t_count, x.size, ch, f0, nf, d_coef.data_ptr())
+                enc.synchronize()
+                assert np.array_equal(bits(d_coef.cpu().numpy()), bits(coef)), f"{kernel} ch={ch}: variant {other} differs"
+            _set_mdct_variant(enc, variant)
 
-    # whole stream on the device: start, noise burst, a tile boundary (row 128k), ragged end
-    launch_and_check(0, 0, L, [0, nf // 2 - 2, (128 * 3) // ch, nf - W])
+    # whole stream on the device: start, noise burst, tile boundaries (rows 128k, 256k), ragged end
+    launch_and_check(0, 0, L, [0, nf // 2 - 2, (128 * 3) // ch, (256 * 5) // ch - 2, nf - W])
     # a shard: frames [f0, nf) from a buffer that holds only [1024 f0 - 512, L)
     f0 = 2 if kernel == "sched" else 3
     if (nf - f0) * ch >= (1793 if kernel == "sched" else 4096):

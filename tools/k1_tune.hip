@@ -224,6 +224,50 @@ int main(int argc, char **argv) {
                   default: return k1::launch_dma<4, 0, 1>(t, p, f0, M, c, s);
                 }
               }},
+      // k_mdct_fwd_st: the table from SGPRs, lanes <-> rows (K1_FILTER='[cand]' K1_ROUNDS=4 compares interleaved)
+      Variant{"[cand] dma 128x128 PRIO 1 (shipped until round 3), the channel count's own loader",
+              [](const DeviceTables &t, const PcmView &p, uint64_t f0, uint32_t M, float *c, hipStream_t s) {
+                switch (p.ch) {
+                  case 1: return k1::launch_dma<4, 1, 1>(t, p, f0, M, c, s);
+                  case 2: return k1::launch_dma<4, 2, 1>(t, p, f0, M, c, s);
+                  case 4: return k1::launch_dma<4, 4, 1>(t, p, f0, M, c, s);
+                  case 8: return k1::launch_dma<4, 8, 1>(t, p, f0, M, c, s);
+                  default: return k1::launch_dma<4, 0, 1>(t, p, f0, M, c, s);
+                }
+              }},
+      Variant{"[cand] st 8 waves 256x64 bk16 d4 PRIO 1, the channel count's own loader (SHIPPED, 4096..8191 rows)",
+              [](const DeviceTables &t, const PcmView &p, uint64_t f0, uint32_t M, float *c, hipStream_t s) {
+                switch (p.ch) {
+                  case 1: return k1::launch_st<4, 1, 1, 4>(t, p, f0, M, c, s);
+                  case 2: return k1::launch_st<4, 2, 1, 4>(t, p, f0, M, c, s);
+                  case 4: return k1::launch_st<4, 4, 1, 4>(t, p, f0, M, c, s);
+                  case 8: return k1::launch_st<4, 8, 1, 4>(t, p, f0, M, c, s);
+                  default: return k1::launch_st<4, 0, 1, 4>(t, p, f0, M, c, s);
+                }
+              }},
+      Variant{"[cand] st 16 waves 256x128 bk16 d4 PRIO 2, the channel count's own loader (SHIPPED, >= 8192 rows)",
+              [](const DeviceTables &t, const PcmView &p, uint64_t f0, uint32_t M, float *c, hipStream_t s) {
+                switch (p.ch) {
+                  case 1: return k1::launch_st<4, 1, 2, 4, 16>(t, p, f0, M, c, s);
+                  case 2: return k1::launch_st<4, 2, 2, 4, 16>(t, p, f0, M, c, s);
+                  case 4: return k1::launch_st<4, 4, 2, 4, 16>(t, p, f0, M, c, s);
+                  case 8: return k1::launch_st<4, 8, 2, 4, 16>(t, p, f0, M, c, s);
+                  default: return k1::launch_st<4, 0, 2, 4, 16>(t, p, f0, M, c, s);
+                }
+              }},
+      Variant{"[cand] st 8 waves bk16 d2 PRIO 1", k1::launch_st<4, 2, 1>},
+      Variant{"[cand] st 16 waves bk32 d4 PRIO 2", k1::launch_st<4, 2, 2, 4, 16, 32>},
+      Variant{"[st] 8 waves bk16 d2 PRIO 0", k1::launch_st<4, 2, 0>},
+      Variant{"[st] 16 waves bk16 d2 PRIO 0", k1::launch_st<4, 2, 0, 2, 16, 16>},
+      Variant{"[st] 16 waves bk16 d4 PRIO 0", k1::launch_st<4, 2, 0, 4, 16, 16>},
+      Variant{"[st] 16 waves bk32 d2 PRIO 2", k1::launch_st<4, 2, 2, 2, 16, 32>},
+      // ablations (results are wrong by construction)
+      Variant{"[abl] st 16 waves bk16 d4 PRIO 2: table address does not advance (scalar cache hits)", k1::launch_st<4, 2, 2, 4, 16, 16, 1>},
+      Variant{"[abl] st 16 waves bk16 d4 PRIO 2: no staging, no barrier", k1::launch_st<4, 2, 2, 4, 16, 16, 2>},
+      Variant{"[abl] st 16 waves bk16 d4 PRIO 2: neither", k1::launch_st<4, 2, 2, 4, 16, 16, 3>},
+      Variant{"[abl] st 8 waves bk16 d4 PRIO 1: table address does not advance", k1::launch_st<4, 2, 1, 4, 8, 16, 1>},
+      Variant{"[abl] st 8 waves bk16 d4 PRIO 1: no staging, no barrier", k1::launch_st<4, 2, 1, 4, 8, 16, 2>},
+      Variant{"[abl] st 8 waves bk16 d4 PRIO 1: neither", k1::launch_st<4, 2, 1, 4, 8, 16, 3>},
       Variant{"SHIPPED sched 64x128 256thr (513..4095 rows)", k1::launch_sched<64, 128, 16, 4>},
       Variant{"SHIPPED small 32x32 t2x2 256thr, hand-scheduled (<= 256 rows)", k1::launch_small<2>},
       Variant{"SHIPPED small 32x64 t2x4 256thr, hand-scheduled (257..512 rows)", k1::launch_small<4>},
@@ -291,7 +335,13 @@ int main(int argc, char **argv) {
   unsigned long long *h_probe;
   CHECK(hipHostMalloc(reinterpret_cast<void **>(&h_probe), 64, hipHostMallocDefault));
   const double macs = (double)M * 1024.0 * 2048.0;
+  // K1_FILTER=<substring>: only the variants whose name contains it;  K1_ROUNDS=<n>: the whole list n times
+  // (the clock the chip holds drifts by a few per cent from one measurement to the next: compare interleaved)
+  const char *filter = getenv("K1_FILTER");
+  const int rounds = getenv("K1_ROUNDS") ? atoi(getenv("K1_ROUNDS")) : 1;
+  for (int round = 0; round < rounds; ++round)
   for (auto &v : vs) {
+    if (filter && v.name.find(filter) == std::string::npos) continue;
     CHECK(hipMemset(d_out, 0xFF, (size_t)M * 1024 * 4));
     {
       const hipError_t first = v.fn(tb, pcm, 0, M, d_out, 0);
