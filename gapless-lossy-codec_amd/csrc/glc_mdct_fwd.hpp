@@ -10,12 +10,18 @@
 // What is in this file - exactly the kernels libglc_hip.so instantiates (launch_mdct_forward in
 // glc_kernels.hip); every other shape, schedule and ablation that was measured lives in
 // tools/k1_variants.hpp beside the tuning harness tools/k1_tune.hip:
-//   k_mdct_fwd_dma     launches of >= 4096 rows (BASELINE config 2 = 8192): 128x128 tile, 512 threads,
-//                      4x8 outputs per lane, table tile copied global -> LDS by LDS-DMA two stages ahead
-//                      (3-slot ring), one counted vmcnt wait per stage; PCM tile by one dwordx4 per lane
-//                      and stage when the stream has 1 / 2 / 4 / 8 channels (CH), one dword per
-//                      (row, sample) otherwise (CH = 0); issue priority lowered by quarter of the i loop
-//                      (PRIO = 1), A rows padded in LDS (GLC_K1_A_STRIDE).
+//   k_mdct_fwd_st      launches of >= 4096 rows (BASELINE config 2 = 8192): a wave's lanes hold 256 ROWS
+//                      (4 each) and share 8 columns, so the table values are wave-uniform and come by scalar
+//                      loads straight from the table into SGPRs; the windowed samples by one ds_read_b128
+//                      per i-step from a 3-slot LDS ring; 4 i-steps per fetch, a group ahead.  256x128
+//                      tile / 1024 threads (one workgroup per CU, priority by distance from the barrier) or
+//                      256x64 / 512 (two per CU, priority by quarter of the i loop), chosen per launch by
+//                      the fill of its last round of tiles; PCM tile by dwordx4 segments when the stream has
+//                      1 / 2 / 4 / 8 channels (CH), one dword per (row, sample) otherwise (CH = 0).
+//   k_mdct_fwd_dma     the kernel of rounds 2 / 3 for the same launches, now behind
+//                      glc_debug_set_mdct_variant(ctx, 1): 128x128 tile, 512 threads, 4x8 outputs per lane
+//                      with lanes <-> columns, both operands from LDS (table tile by LDS-DMA two stages
+//                      ahead); 8-9 % slower on real samples because the chip holds less clock under it.
 //   k_mdct_fwd_sched   1793..4095 rows, as <64,128,16,4>: 64x128 tile, 256 threads, hand-scheduled
 //                      inline-asm i-steps (step4), LDS operand prefetch, XCD-aware tile map, register
 //                      staging, classic double buffer.

@@ -145,14 +145,29 @@ int main(int argc, char **argv) {
     for (int r = 0; r < reps; ++r) {
       hipLaunchKernelGGL(k_fill_random, dim3(1024), dim3(256), 0, 0, d_pcm, n_samples, 0x9E3779B9u * (unsigned)(r + 1));
       hipLaunchKernelGGL(k_naive, dim3(4, M), dim3(256), 0, 0, tb, pcm, 0ll, M, d_ref);
-      // the instantiations the library ships (glc_kernels.hip kK1Prio = 1); below 4096 rows the short-clip /
-      // 64 x 128 kernels the library would take for that row count
+      // the instantiations the library ships (glc_kernels.hip launch_mdct_forward): k_mdct_fwd_st with 16 and
+      // with 8 waves per workgroup, the channel count's segment loader and the per-row loader in turn; below
+      // 4096 rows the short-clip / 64 x 128 kernels the library would take for that row count
       hipError_t launched;
       if (M <= 640) launched = k1::launch_small<2>(tb, pcm, 0, M, d_out, 0);
       else if (M <= 1792) launched = k1::launch_small<4>(tb, pcm, 0, M, d_out, 0);
       else if (M < 4096) launched = k1::launch_sched<64, 128, 16, 4>(tb, pcm, 0, M, d_out, 0);
-      else launched = (r & 1) ? (ch == 2 ? k1::launch_dma<4, 2, 1>(tb, pcm, 0, M, d_out, 0) : k1::launch_dma<4, 0, 1>(tb, pcm, 0, M, d_out, 0))
-                              : k1::launch_dma<4, 0, 1>(tb, pcm, 0, M, d_out, 0);
+      else {
+        const bool seg = (r & 2) == 0 && (ch == 1 || ch == 2 || ch == 4 || ch == 8);
+        if (r & 1) {
+          launched = !seg ? k1::launch_st<4, 0, 1, 4, 8>(tb, pcm, 0, M, d_out, 0)
+                   : ch == 1 ? k1::launch_st<4, 1, 1, 4, 8>(tb, pcm, 0, M, d_out, 0)
+                   : ch == 2 ? k1::launch_st<4, 2, 1, 4, 8>(tb, pcm, 0, M, d_out, 0)
+                   : ch == 4 ? k1::launch_st<4, 4, 1, 4, 8>(tb, pcm, 0, M, d_out, 0)
+                             : k1::launch_st<4, 8, 1, 4, 8>(tb, pcm, 0, M, d_out, 0);
+        } else {
+          launched = !seg ? k1::launch_st<4, 0, 2, 4, 16>(tb, pcm, 0, M, d_out, 0)
+                   : ch == 1 ? k1::launch_st<4, 1, 2, 4, 16>(tb, pcm, 0, M, d_out, 0)
+                   : ch == 2 ? k1::launch_st<4, 2, 2, 4, 16>(tb, pcm, 0, M, d_out, 0)
+                   : ch == 4 ? k1::launch_st<4, 4, 2, 4, 16>(tb, pcm, 0, M, d_out, 0)
+                             : k1::launch_st<4, 8, 2, 4, 16>(tb, pcm, 0, M, d_out, 0);
+        }
+      }
       CHECK(launched);
       hipLaunchKernelGGL(k_count_diff, dim3(1024), dim3(256), 0, 0, reinterpret_cast<const unsigned *>(d_ref),
                          reinterpret_cast<const unsigned *>(d_out), (size_t)M * 1024, d_bad);

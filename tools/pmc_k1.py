@@ -35,7 +35,7 @@ def main():
     bench = ["python3", os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--lean"]
     got = {}
     lines = [f"# rocprofv3 --pmc ({len(PASSES)} separate passes) -- python3 bench.py --steps 5 --warmup 1 --lean",
-             f"# kernel {K1}<4, 2>, 8192 rows x 1024 coefficients (BASELINE config 2, chord input); second half of the dispatches",
+             f"# kernel {K1} (the shipped instance for stereo), 8192 rows x 1024 coefficients (BASELINE config 2, chord input); second half of the dispatches",
              "# SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* in quad-cycles summed over all SIMDs; GRBM_GUI_ACTIVE, SQ_BUSY_CYCLES in cycles summed over 8 XCDs / 32 SEs",
              "# pass counter n mean"]
     for i, counters in enumerate(PASSES, 1):

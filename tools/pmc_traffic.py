@@ -22,8 +22,9 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-K1 = "k_mdct_fwd_dma"
+K1 = "k_mdct_fwd_st"
 ALGO_K1_BYTES = 8388608 * 4 + 8 * 1024 * 1024 + 8192 * 1024 * 4   # PCM once + table once + coefficient write
+PCM_ONCE = 8388608 * 4 * 129 / 128   # every PCM byte once per row tile of 128 frames (+ the 1024-sample halo)
 
 
 def run_pass(counters, cmd, outdir):
@@ -70,11 +71,13 @@ def main():
     for name, pattern in (("calib_read_b32", "4 B/lane coalesced global_load_dword"),
                           ("calib_read_b128", "16 B/lane coalesced global_load_dwordx4"),
                           ("calib_read_segments", "K1 PCM: 128-B segments, 8 lanes x buffer_load_dwordx4, 8 KiB apart"),
-                          ("calib_read_lds_dma", "K1 table: 512-B rows by global_load_lds_dwordx4")):
+                          ("calib_read_lds_dma", "k_mdct_fwd_dma's table: 512-B rows by global_load_lds_dwordx4"),
+                          ("calib_read_scalar", "K1 table: 32-B pieces of 4-KiB rows by s_load_dwordx8")):
         v, n = pick(cf, name, "FETCH_SIZE")
         factors[name] = {"pattern": pattern, "FETCH_SIZE_KB": v, "dispatches": n,
                          "counter_bytes_per_true_byte": None if v is None else round(v / true_kb, 4)}
-    for name, pattern in (("calib_write_b32", "4 B/lane coalesced store"), ("calib_write_b128", "16 B/lane coalesced store")):
+    for name, pattern in (("calib_write_b32", "4 B/lane coalesced store"), ("calib_write_b128", "16 B/lane coalesced store"),
+                          ("calib_write_rows", "K1 output: 2 x 16 B per lane and row, a lane's rows 4 KiB apart")):
         v, n = pick(cw, name, "WRITE_SIZE")
         factors[name] = {"pattern": pattern, "WRITE_SIZE_KB": v, "dispatches": n,
                          "counter_bytes_per_true_byte": None if v is None else round(v / true_kb, 4)}
@@ -90,12 +93,15 @@ def main():
         m, _ = pick(bh, needle, "TCC_MISS_sum")
         kernels[label] = {"kernel": needle, "dispatches": n, "FETCH_SIZE_KB_raw": f, "WRITE_SIZE_KB_raw": w,
                           "TCC_HIT_sum": h, "TCC_MISS_sum": m}
-    # K1's reads are the two calibrated patterns; if their factors agree, one correction serves the kernel
-    fs = [factors[k]["counter_bytes_per_true_byte"] for k in ("calib_read_segments", "calib_read_lds_dma")]
-    fw = factors["calib_write_b128"]["counter_bytes_per_true_byte"]
+    # K1 reads with two patterns that the counter weighs differently (FETCH_SIZE reports half the bytes of the
+    # dwordx4 segment reads and all the bytes of the scalar loads): one raw figure, two unknowns.  The PCM
+    # side is pinned from the algorithm - with the XCD-aware tile map the 8 workgroups that share a row tile
+    # sit on one XCD, so a PCM byte misses that L2 once: PCM_ONCE bytes - and the rest of the raw figure is the table.
+    fs = [factors[k]["counter_bytes_per_true_byte"] for k in ("calib_read_segments", "calib_read_scalar")]
+    fw = factors["calib_write_rows"]["counter_bytes_per_true_byte"]
     k1 = kernels["K1"]
     out = {
-        "kernel": "glc::k1::k_mdct_fwd_dma<4, 2, 1, false> (128x128 tile, 512 threads, table tile by LDS-DMA, PCM by dwordx4 segments)",
+        "kernel": "glc::k1::k_mdct_fwd_st<4, 2, 2, 4, 16, 16, 0> (256x128 tile, 1024 threads, table values by scalar loads, PCM by dwordx4 segments)",
         "commit": args.commit,
         "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --steps 10, corrected by the "
                   "factors tools/fetch_calib.hip measures for K1's own access patterns in the same session",
@@ -104,11 +110,14 @@ def main():
         "algorithmic_bytes_per_launch": ALGO_K1_BYTES,
     }
     if None not in fs and fw and k1["FETCH_SIZE_KB_raw"] is not None:
-        read_factor = sum(fs) / len(fs)
-        rd = k1["FETCH_SIZE_KB_raw"] * 1024.0 / read_factor
+        raw = k1["FETCH_SIZE_KB_raw"] * 1024.0
+        pcm_once = PCM_ONCE
+        table = max(0.0, raw - fs[0] * pcm_once) / fs[1]
+        rd = pcm_once + table
         wr = k1["WRITE_SIZE_KB_raw"] * 1024.0 / fw
-        out["read_correction"] = {"segments": fs[0], "lds_dma": fs[1], "applied": round(read_factor, 4),
-                                  "spread": round(abs(fs[0] - fs[1]), 4)}
+        out["read_correction"] = {"segments": fs[0], "scalar": fs[1],
+                                  "pcm_bytes_assumed": int(pcm_once), "table_bytes": int(table),
+                                  "bounds_if_one_pattern": [int(raw / max(fs)), int(raw / min(fs))]}
         out["write_correction"] = fw
         out["read_bytes_per_launch"] = int(rd)
         out["write_bytes_per_launch"] = int(wr)

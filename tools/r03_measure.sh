@@ -3,7 +3,7 @@
 # Usage: bash tools/r03_measure.sh <commit>     -> gpurun_out/r3z/
 set -u
 C=${1:-unknown}
-O=gpurun_out/r3z
+O=${GLC_MEASURE_OUT:-gpurun_out/r3z}
 R=$(pwd)
 mkdir -p $O
 python tools/dump_d1_rows.py > $O/dump.txt 2>&1
