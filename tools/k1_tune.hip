@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "glc_mdct_fwd.hpp"  // namespace glc::k1: the kernels the library ships
+#include "k1_row_variant.hpp"  // k_mdct_fwd_row: one row per lane (measured, not adopted)
 #include "k1_variants.hpp"   // namespace glc::k1x: every other shape / schedule / ablation (tuning only)
 
 #pragma clang fp contract(off)
@@ -239,6 +240,22 @@ int main(int argc, char **argv) {
                   default: return k1::launch_dma<4, 0, 1>(t, p, f0, M, c, s);
                 }
               }},
+      // k_mdct_fwd_row (tools/k1_row_variant.hpp): one row per lane, C columns per wave from SGPRs; measured for
+      // launches below 4096 rows and not adopted (K1_FILTER='[row]' build/k1_tune <frames> 2 20)
+      Variant{"[row] C=2 bk32, segment loader (stereo)", k1::launch_row<2, 2, 32>},
+      Variant{"[row] C=4 bk32, segment loader (stereo)", k1::launch_row<4, 2, 32>},
+      Variant{"[row] C=8 bk32, segment loader (stereo)", k1::launch_row<8, 2, 32>},
+      Variant{"[row] C=2 bk64, segment loader (stereo)", k1::launch_row<2, 2, 64>},
+      Variant{"[row] C=4 bk64, segment loader (stereo)", k1::launch_row<4, 2, 64>},
+      Variant{"[row] C=8 bk64, segment loader (stereo)", k1::launch_row<8, 2, 64>},
+      Variant{"[row] C=4 bk16, segment loader (stereo)", k1::launch_row<4, 2, 16>},
+      Variant{"[row] C=8 bk16, segment loader (stereo)", k1::launch_row<8, 2, 16>},
+      Variant{"[row] C=4 bk32, per-row loader", k1::launch_row<4, 0, 32>},
+      Variant{"[row] C=8 bk32, per-row loader", k1::launch_row<8, 0, 32>},
+      Variant{"[row] SHIPPED small 2x2 (<= 640 rows)", k1::launch_small<2>},
+      Variant{"[row] SHIPPED small 2x4 (<= 1792 rows)", k1::launch_small<4>},
+      Variant{"[row] SHIPPED sched 64x128 (1793..4095 rows)", k1::launch_sched<64, 128, 16, 4>},
+      Variant{"[row] st 8 waves (>= 4096 rows)", k1::launch_st<4, 2, 1, 4>},
       // k_mdct_fwd_st: the table from SGPRs, lanes <-> rows (K1_FILTER='[cand]' K1_ROUNDS=4 compares interleaved)
       Variant{"[cand] dma 128x128 PRIO 1 (shipped until round 3), the channel count's own loader",
               [](const DeviceTables &t, const PcmView &p, uint64_t f0, uint32_t M, float *c, hipStream_t s) {
