@@ -9,13 +9,15 @@
 //   1792 rows  C=8: 0.152            shipped: 0.187                    -19 %
 //   3000 rows  C=8: 0.255            shipped 64 x 128 kernel: 0.309    -17 %
 //   4094 rows  C=8: 0.304            k_mdct_fwd_st, 8 waves: 0.291     worse
-// Why it does not deliver what its operand traffic promises: a group's time goes with the NUMBER of scalar
-// loads in it - about 60 cycles per s_load and wave when every load is a cache line of its own (table rows
-// are 4 KiB apart): C=8 250 cycles per group of 4 loads, C=4 500 per 8, C=2 1670 per 16 - and scalar loads only
-// allow lgkmcnt(0), so there is never more than one group in flight.  k_mdct_fwd_st issues the same load once
-// per 32 packed operations and four waves per SIMD hide it; a lane tile of C outputs issues it once per C.
-// A table copy laid out [column group][i][8] would make a group two 64-byte loads; not built (an 8 MiB table
-// per context for launches of 10-45 seconds of audio).
+// Why it does not deliver what its operand traffic promises: scalar loads only allow lgkmcnt(0), so there is
+// never more than one group of operands in flight, and a group (32 table dwords: the SGPR file holds two) is
+// 4 i-steps of C=8, 8 of C=4, 16 of C=2 - 32 packed operations, 128 cycles of arithmetic against a round trip of
+// 250-500 cycles.  k_mdct_fwd_st has the same one group in flight but four waves per SIMD to hide it; a launch
+// that puts one or two waves on a SIMD has not.  On top of that a group's time grows with the number of scalar
+// loads in it when every load is a cache line of its own (table rows are 4 KiB apart): C=8 250 cycles per group
+// of 4 loads, C=4 500 per 8, C=2 1670 per 16.  k_mdct_fwd_row8 checks that part: with a table copy laid out
+// [column group][i][8] a group is two 64-byte loads - 1024 rows 0.118 ms instead of 0.147, 3000 rows 0.234 instead
+// of 0.254, but 172 rows 0.059 (one round trip per 4 i-steps stays).  Not worth 8 MiB more per context.
 #pragma once
 #include "glc_mdct_fwd.hpp"
 
@@ -358,6 +360,172 @@ __global__ __launch_bounds__(256) void k_mdct_fwd_row(DeviceTables tb, PcmView p
       *reinterpret_cast<float2 *>(dst + 2 * c) = o;
     }
   }
+}
+
+// ---- the same kernel for C = 8 reading a table copy laid out [column group of 8][i][8] (tb.cos is borrowed for
+// its address by the harness): the 8 values of two consecutive i-steps are ONE 64-byte scalar load.
+typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+struct SrOps8 {  // 4 i-steps
+  f32x4 a;
+  u32x16 b01, b23;
+};
+template <int II>
+__device__ __forceinline__ void sr8_fetch(SrOps8 &o, unsigned a_addr, const unsigned *bgrp) {
+  asm volatile("s_load_dwordx16 %0, %2, %c3\n\ts_load_dwordx16 %1, %2, %c4"
+               : "=&s"(o.b01), "=&s"(o.b23)
+               : "s"(bgrp), "i"(II * 32), "i"(II * 32 + 64)
+               : "memory");
+  asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=&v"(o.a) : "v"(a_addr), "i"(II * 4) : "memory");
+}
+__device__ __forceinline__ void sr8_wait(SrOps8 &o) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(o.b01), "+s"(o.b23)::"memory");
+  asm volatile("" : "+v"(o.a)::"memory");
+}
+__device__ __forceinline__ void sr8_mac(f32x2 (&acc)[4], const SrOps8 &o) {
+  sr_mac2(acc, o.a.xy, o.b01.lo, o.b01.hi);
+  sr_mac2(acc, o.a.zw, o.b23.lo, o.b23.hi);
+}
+
+template <int CH = 0, int BK = 32>
+__global__ __launch_bounds__(256) void k_mdct_fwd_row8(DeviceTables tb, PcmView pcm, long long frame_begin, unsigned M,
+                                                        float *__restrict__ coef) {
+  constexpr int C = 8, BM = 64, BN = 4 * C, RING = 3, G = 4;
+  constexpr int kAS = BK + 4;
+  constexpr int kThreads = 256;
+  constexpr int kNTiles = kHopI / BN;
+  static_assert(CH == 1 || CH == 2 || CH == 4 || CH == 8, "segment loader shapes (tuning variant: no per-row loader)");
+  constexpr int kPieces = BM * BK / 4 / kThreads;
+  __shared__ __attribute__((aligned(16))) float As[RING][BM * kAS];
+  const int tid = threadIdx.x;
+  const int n_tile = blockIdx.x % kNTiles;
+  const int m_tile = blockIdx.x / kNTiles;
+  const int m0 = m_tile * BM;
+  const int n0 = n_tile * BN;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const long long ch = pcm.ch;
+  const long long f0 = frame_begin + m0 / pcm.ch;
+  const long long e_first = (f0 * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * ch;
+  long long e_end = static_cast<long long>(pcm.t_count) * ch;
+  const long long n_rel = static_cast<long long>(pcm.n_samples) - static_cast<long long>(pcm.t0) * ch;
+  if (e_end > n_rel) e_end = n_rel;
+  const long long e_base = e_first < 0 ? 0 : e_first;
+  long long e_cnt = e_end - e_base;
+  if (e_cnt < 0) e_cnt = 0;
+  if (e_cnt > (1ll << 28)) e_cnt = 1ll << 28;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(pcm.p + e_base), 0, static_cast<int>(e_cnt * 4), 0x00020000);
+  unsigned a_off[kPieces];
+  const unsigned i_bytes = static_cast<unsigned>(ch * 4);
+  constexpr int kSegLanes = BK / 4 * CH;
+  constexpr int kSegStep = kThreads / kSegLanes;
+  const int seg_fl = tid / kSegLanes;
+  const int seg_o = (tid % kSegLanes) * 4;
+#pragma unroll
+  for (int p = 0; p < kPieces; ++p) {
+    a_off[p] = 0x80000000u;
+    const unsigned row0 = m0 + (seg_fl + p * kSegStep) * CH;
+    if (row0 < M) {
+      const long long f = frame_begin + row0 / CH;
+      const long long e_row = (f * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * CH;
+      a_off[p] = static_cast<unsigned>((e_row - e_base + seg_o) * 4);
+    }
+  }
+  constexpr int kWin = CH == 1 ? 4 : CH == 2 ? 2 : 1;
+  f32x4 a_seg[kPieces];
+  float w_seg[kWin];
+  auto issue_a = [&](int i0) {
+#pragma unroll
+    for (int p = 0; p < kPieces; ++p) {
+      const unsigned o = a_off[p] + static_cast<unsigned>(i0) * i_bytes;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(a_seg[p]) : "v"(o), "s"(a_rsrc) : "memory");
+    }
+    const float *w = tb.window + i0 + seg_o / CH;
+#pragma unroll
+    for (int k = 0; k < kWin; ++k) w_seg[k] = w[k];
+  };
+  auto store_a = [&](int slot) {
+#pragma unroll
+    for (int p = 0; p < kPieces; ++p) {
+      f32x4 v = a_seg[p];
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)::"memory");
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = seg_o + j;
+        const int ii = e / CH;
+        As[slot][((seg_fl + p * kSegStep) * CH + e % CH) * kAS + ii] = mul_rn(v[j], w_seg[j / CH < kWin ? j / CH : 0]);
+      }
+    }
+  };
+  f32x2 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = f32x2{0.0f, 0.0f};
+  constexpr int kStages = kFrameI / BK;
+  issue_a(0);
+  store_a(0);
+  issue_a(BK);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  const unsigned a_lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(&As[0][lane * kAS]));
+  // this wave's column group in the [group][i][8] copy (borrowed field: tb.cos)
+  const unsigned *b_base = reinterpret_cast<const unsigned *>(tb.cos) + static_cast<size_t>(n0 / 8 + wave) * (kFrameI * 8);
+  SrOps8 X, Y;
+  sr8_fetch<0>(X, a_lds0, b_base);
+  sr8_wait(X);
+#pragma unroll 1
+  for (int s = 0; s < kStages; ++s) {
+    const int slot = s % 3, nslot = (s + 1) % 3;
+    const unsigned a_addr = a_lds0 + slot * (BM * kAS * 4);
+    const unsigned a_next = a_lds0 + nslot * (BM * kAS * 4);
+    const unsigned *brow = b_base + static_cast<size_t>(s) * (BK * 8);
+    const unsigned *brow_next = b_base + static_cast<size_t>((s + 1) & (kStages - 1)) * (BK * 8);
+#define GLC_SR8_GROUP(CUR, NXT, II)                                             \
+  do {                                                                          \
+    if constexpr ((II) + G < BK) sr8_fetch<((II) + G) % BK>(NXT, a_addr, brow);  \
+    else sr8_fetch<0>(NXT, a_next, brow_next);                                  \
+    sr8_mac(acc, CUR);                                                          \
+    if constexpr ((II) + G == BK / 2) {                                         \
+      store_a(nslot);                                                           \
+      sr8_wait(NXT);                                                            \
+      __builtin_amdgcn_s_barrier();                                             \
+      issue_a(((s + 2) & (kStages - 1)) * BK);                                  \
+    } else {                                                                    \
+      sr8_wait(NXT);                                                            \
+    }                                                                           \
+  } while (0)
+    GLC_SR8_GROUP(X, Y, 0);
+    GLC_SR8_GROUP(Y, X, 4);
+    GLC_SR8_GROUP(X, Y, 8);
+    GLC_SR8_GROUP(Y, X, 12);
+    if constexpr (BK > 16) {
+      GLC_SR8_GROUP(X, Y, 16);
+      GLC_SR8_GROUP(Y, X, 20);
+      GLC_SR8_GROUP(X, Y, 24);
+      GLC_SR8_GROUP(Y, X, 28);
+    }
+#undef GLC_SR8_GROUP
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned row = m0 + lane;
+  if (row < M) {
+    float *dst = coef + static_cast<size_t>(row) * kHopI + n0 + C * wave;
+#pragma unroll
+    for (int c = 0; c < C / 2; ++c) {
+      float2 o;
+      o.x = mul_rn(acc[c].x, tb.norm); o.y = mul_rn(acc[c].y, tb.norm);
+      *reinterpret_cast<float2 *>(dst + 2 * c) = o;
+    }
+  }
+}
+template <int CH = 0, int BK = 32>
+inline hipError_t launch_row8(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M, float *coef,
+                              hipStream_t s) {
+  if (M == 0) return hipSuccess;
+  if (pcm.ch != static_cast<uint32_t>(CH)) return hipErrorInvalidValue;
+  const unsigned m_tiles = (M + 63) / 64;
+  hipLaunchKernelGGL((k_mdct_fwd_row8<CH, BK>), dim3(m_tiles * (kHopI / 32)), dim3(256), 0, s, t, pcm,
+                     static_cast<long long>(frame_begin), M, coef);
+  return hipGetLastError();
 }
 
 template <int C, int CH = 0, int BK = 32>

@@ -129,7 +129,16 @@ int main(int argc, char **argv) {
   CHECK(hipMemcpy(d_win, h_win.data(), 2048 * 4, hipMemcpyHostToDevice));
   CHECK(hipMemcpy(d_pcm, h_pcm.data(), n_samples * 4, hipMemcpyHostToDevice));
 
+  // [column group of 8][i][8] copy of the table for k_mdct_fwd_row8 (tools/k1_row_variant.hpp), through the
+  // field the forward kernels do not use
+  std::vector<float> h_t8(h_cos_t.size());
+  for (size_t i = 0; i < 2048; ++i)
+    for (size_t k = 0; k < 1024; ++k) h_t8[((k / 8) * 2048 + i) * 8 + k % 8] = h_cos_t[i * 1024 + k];
+  float *d_t8;
+  CHECK(hipMalloc(&d_t8, h_t8.size() * 4));
+  CHECK(hipMemcpy(d_t8, h_t8.data(), h_t8.size() * 4, hipMemcpyHostToDevice));
   DeviceTables tb{};
+  tb.cos = d_t8;
   tb.cos_t = d_cos_t;
   tb.window = d_win;
   tb.norm = 0.044194173f;
@@ -250,6 +259,8 @@ int main(int argc, char **argv) {
       Variant{"[row] C=8 bk64, segment loader (stereo)", k1::launch_row<8, 2, 64>},
       Variant{"[row] C=4 bk16, segment loader (stereo)", k1::launch_row<4, 2, 16>},
       Variant{"[row] C=8 bk16, segment loader (stereo)", k1::launch_row<8, 2, 16>},
+      Variant{"[row] C=8 bk16, table copy [group][i][8]: two 64-byte scalar loads per 4 i-steps", k1::launch_row8<2, 16>},
+      Variant{"[row] C=8 bk32, table copy [group][i][8]", k1::launch_row8<2, 32>},
       Variant{"[row] C=4 bk32, per-row loader", k1::launch_row<4, 0, 32>},
       Variant{"[row] C=8 bk32, per-row loader", k1::launch_row<8, 0, 32>},
       Variant{"[row] SHIPPED small 2x2 (<= 640 rows)", k1::launch_small<2>},
