@@ -1001,7 +1001,7 @@ namespace {
 
 // ---------------------------------------------------------------------------- launchers
 
-// Which kernel takes a launch of 4096 rows or more (the rest of the dispatch is by row count alone):
+// Which kernel takes a launch of 3584 / 4096 rows or more (the rest of the dispatch is by row count alone):
 //   st 16 waves  256 x 128 tiles, one 1024-thread workgroup per CU: a launch runs in rounds of 256 tiles;
 //   st 8 waves   256 x 64 tiles, two 512-thread workgroups per CU: rounds of 512, and a CU with one
 //                workgroup left finishes it in about 0.6 of a round.
@@ -1044,11 +1044,14 @@ hipError_t launch_mdct_forward(const DeviceTables &t, const PcmView &pcm, uint64
   // A clip of a few seconds is latency-bound by one wave's chain of 2048 dependent i-steps, not by
   // throughput, and the length of a step is the lane tile: cut it until every SIMD has a wave of its own
   // (glc_mdct_fwd.hpp k_mdct_fwd_small: 2 x 2 outputs per lane, then 2 x 4).  Measured against the 4 x 8
-  // kernels (profiles/r03_k1_tune_short_clips.txt): 172 rows 0.058 ms (4 x 8 tile: 0.19), 600 rows 0.10,
-  // 1024 rows 0.11, 1536 rows 0.15; at 2048 rows the 64 x 128 kernel draws level (0.19).
+  // kernels (profiles/r03_k1_tune_short_clips.txt, r03_k1_tune_mid_sizes.txt): 172 rows 0.053-0.058 ms (4 x 8
+  // tile: 0.19), 600 rows 0.10, 1024 rows 0.11, 2048 rows 0.20, 3072 rows 0.28; a launch of 256-row tiles costs
+  // 0.28-0.34 ms however few rows it has (one workgroup's chain) and draws level at about 3500 rows - when
+  // the channel count has a segment loader; with one dword per (row, sample) only at 4096.  (Rounds 1-3 kept a
+  // 64 x 128 kernel for 1793..4095 rows: 0.22 ms at 2048 rows, 0.34 at 3072 - slower than both neighbours.)
+  const bool seg = pcm.ch == 1 || pcm.ch == 2 || pcm.ch == 4 || pcm.ch == 8;
   if (M <= 640) return k1::launch_small<2>(t, pcm, frame_begin, M, coef, s);
-  if (M <= 1792) return k1::launch_small<4>(t, pcm, frame_begin, M, coef, s);
-  if (M < 4096) return k1::launch_sched<64, 128, 16, 4>(t, pcm, frame_begin, M, coef, s);  // 1793..4095 rows: more workgroups than the 128-row tile gives
+  if (M < (seg ? 3584u : 4096u)) return k1::launch_small<4>(t, pcm, frame_begin, M, coef, s);
   // variant (include/glc_debug.h glc_debug_set_mdct_variant): 0 = shipped, 1 = round 3's kernel, 2 / 3 = one form for every launch
   if (variant == 1) return launch_dma_ch(t, pcm, frame_begin, M, coef, s);
   if (variant == 2) return launch_st_ch<8>(t, pcm, frame_begin, M, coef, s);

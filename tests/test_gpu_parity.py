@@ -706,10 +706,10 @@ def test_long_ragged_streams_and_shards(torch_cuda, ch):
 
 
 # ---------------------------------------------------------------------------------------
-# Direct coefficient-bit parity of the two hand-scheduled transforms: the
-# launches the benchmark and long streams actually take - k_mdct_fwd_sched (1793..4095 rows) and
-# the five k_mdct_fwd_dma instantiations (>= 4096 rows; ch 1 / 2 / 4 / 8 = dwordx4 segment loader,
-# 3 = per-row loader) - compared f32 bit for f32 bit with the oracle's mdct_block on windows of
+# Direct coefficient-bit parity of the hand-scheduled transforms: the launches the
+# benchmark and long streams actually take - k_mdct_fwd_small<4> at the top of its range (up to 3583 /
+# 4095 rows), k_mdct_fwd_st in both workgroup shapes and round 3's k_mdct_fwd_dma (ch 1 / 2 / 4 / 8 =
+# dwordx4 segment loader, 3 = per-row loader) - compared f32 bit for f32 bit with the oracle's mdct_block on windows of
 # frames: the stream start (leading zero padding), a noise burst, the ragged end (partially
 # out-of-range loads), and the same through a shard whose device buffer starts mid-stream.
 # Reference: src/codec.rs:476-485, :359-374.
@@ -733,11 +733,13 @@ def _set_mdct_variant(ctx, v):
     assert glc_amd.lib.glc_debug_set_mdct_variant(ctx._h, v) == 0
 
 
-# which kernel a launch reaches: by its row count (sched), or pinned through include/glc_debug.h (1 = dma:
-# round 3's kernel, 2 / 3 = k_mdct_fwd_st with 8 / 16 waves per workgroup); "shipped" = the dispatch itself at
-# 8192 + rows (16 waves: the last round of row tiles is full ... more than half full)
-_K1_KERNELS = {"sched": (2300, 0), "dma": (4096 + 333, 1), "st8": (4096 + 333, 2), "st16": (4096 + 333, 3),
-               "shipped": (8192 + 4400, 0)}
+# which kernel a launch reaches: by its row count (small4: the 2 x 4 short-clip kernel, up to 3583 rows - 4095
+# when the channel count has no segment loader; low: the first row counts of k_mdct_fwd_st), or pinned through
+# include/glc_debug.h (1 = dma: round 3's first kernel, 2 / 3 = k_mdct_fwd_st with 8 / 16 waves per workgroup);
+# "shipped" = the dispatch itself at 8192 + rows (16 waves: the last round of row tiles is more than half full)
+_K1_KERNELS = {"small4": (2300, 0), "small4-top": (3500, 0), "low": (3584 + 24, 0), "dma": (4096 + 333, 1),
+               "st8": (4096 + 333, 2), "st16": (4096 + 333, 3), "shipped": (8192 + 4400, 0)}
+_K1_BY_ROWS = ("small4", "small4-top", "low")
 
 
 @pytest.mark.parametrize("ch", [1, 2, 4, 8, 3])
@@ -754,7 +756,7 @@ def test_k1_large_launch_coefficient_bits(torch_cuda, ch, kernel):
 
     def launch_and_check(f0, t0, t_count, windows):
         rows = (nf - f0) * ch
-        assert (1793 <= rows <= 4095) if kernel == "sched" else rows >= 4096
+        assert rows <= 4095 if kernel in _K1_BY_ROWS else rows >= 4096
         lo, hi = t0 * ch, min((t0 + t_count) * ch, x.size)
         d_pcm = torch_cuda.from_numpy(x[lo:hi].copy()).cuda()
         d_coef = torch_cuda.full((rows, 1024), float("nan"), dtype=torch_cuda.float32, device="cuda")
@@ -769,7 +771,7 @@ def test_k1_large_launch_coefficient_bits(torch_cuda, ch, kernel):
             got = coef[(a - f0) * ch:(b - f0) * ch]
             assert np.array_equal(bits(got), bits(ref.coeffs)), \
                 f"{kernel} ch={ch}: {(bits(got) != bits(ref.coeffs)).sum()} coefficient words differ in frames [{a},{b})"
-        if kernel != "sched":  # every row of the launch: the other kernels for this size give the same words
+        if kernel not in _K1_BY_ROWS:  # every row of the launch: the other kernels for this size give the same words
             for other in (1, 2, 3):
                 if other == variant:
                     continue
@@ -784,19 +786,21 @@ def test_k1_large_launch_coefficient_bits(torch_cuda, ch, kernel):
     # whole stream on the device: start, noise burst, tile boundaries (rows 128k, 256k), ragged end
     launch_and_check(0, 0, L, [0, nf // 2 - 2, (128 * 3) // ch, (256 * 5) // ch - 2, nf - W])
     # a shard: frames [f0, nf) from a buffer that holds only [1024 f0 - 512, L)
-    f0 = 2 if kernel == "sched" else 3
-    if (nf - f0) * ch >= (1793 if kernel == "sched" else 4096):
+    f0 = 2 if kernel in _K1_BY_ROWS else 3
+    if (nf - f0) * ch >= (1793 if kernel in _K1_BY_ROWS else 4096):
         launch_and_check(f0, f0 * 1024 - 512, L - (f0 * 1024 - 512), [f0, nf // 2 - 1, nf - W])
 
 
 def test_k1_small_launch_tile_edges(torch_cuda):
-    """The short-clip transform (k_mdct_fwd_small: 2 x 2 outputs per lane up to 640 rows, 2 x 4 up to
-    1792) across its 32-row tile edges, with partial last tiles, ragged ends, and at both ends of each range."""
-    for ch, frames in ((1, 70), (2, 255), (3, 170), (8, 64), (2, 320), (1, 641), (2, 500), (3, 597), (8, 224), (5, 300)):
+    """The short-clip transform (k_mdct_fwd_small: 2 x 2 outputs per lane up to 640 rows, 2 x 4 above)
+    across its 32-row tile edges, with partial last tiles, ragged ends, and at both ends of each range
+    (3583 rows with a segment loader, 4095 without)."""
+    for ch, frames in ((1, 70), (2, 255), (3, 170), (8, 64), (2, 320), (1, 641), (2, 500), (3, 597), (8, 224), (5, 300),
+                       (1, 3583), (7, 585)):
         x, sr = _k1_stream(ch, frames, 7 * ch)
         plan = glc_amd.plan_encode(x.size, ch)
         nf = plan.n_frames
-        assert nf * ch <= 1792
+        assert nf * ch <= (3583 if ch in (1, 2, 4, 8) else 4095)
         d_pcm = torch_cuda.from_numpy(x).cuda()
         d_coef = torch_cuda.zeros((nf * ch, 1024), dtype=torch_cuda.float32, device="cuda")
         enc = glc_amd.Encoder(sr)
