@@ -297,6 +297,11 @@ int main(int argc, char **argv) {
                   default: return k1::launch_st<4, 0, 2, 4, 16>(t, p, f0, M, c, s);
                 }
               }},
+      // (2 rows per lane = 8 waves per SIMD was measured with a TR parameter that is not kept: 0.588-0.611 ms
+      // against 0.547-0.554 for the shipped forms in the same process, profiles/r03_k1_tune_st_two_rows.txt; with
+      // 4 i-steps per fetch hipcc ran out of scalar registers there and spilled table values into VGPR lanes
+      // BETWEEN the scalar load and its s_waitcnt - stale values, wrong results, a memory fault: the case
+      // tools/check_isa.py refuses for the shipped kernels)
       Variant{"[cand] st 8 waves bk16 d2 PRIO 1", k1::launch_st<4, 2, 1>},
       Variant{"[cand] st 16 waves bk32 d4 PRIO 2", k1::launch_st<4, 2, 2, 4, 16, 32>},
       Variant{"[st] 8 waves bk16 d2 PRIO 0", k1::launch_st<4, 2, 0>},
