@@ -46,11 +46,13 @@ def main() -> int:
                 first_ds[cur] = True
             elif first_ds.get(cur) and re.match(r"^\s+(s_load|s_buffer_load)", line):
                 bad.append((cur, "scalar load beside counted LDS waits: " + line.strip()))
-        if cur and cur.startswith("k_mdct_fwd") and re.match(r"^\s+(scratch_|buffer_store.*offen.*s\[0:3\]|buffer_load.*off.*s\[0:3\])", line):
+        asm_async = cur and (cur.startswith("k_mdct_fwd") or cur == "k_imdct_apply")  # loads issued and waited for in separate asm statements
+        if asm_async and re.match(r"^\s+(scratch_|buffer_store.*offen.*s\[0:3\]|buffer_load.*off.*s\[0:3\])", line):
             bad.append((cur, "register spill: " + line.strip()))
-        # k_mdct_fwd_st keeps up to 64 table values in SGPRs: a scalar register spilled into VGPR lanes would
-        # put a v_writelane / v_readlane pair into the inner loop
-        if cur and cur.startswith("k_mdct_fwd") and re.match(r"^\s+(v_writelane|v_readlane)", line):
+        # k_mdct_fwd_st / k_imdct_apply keep table values / records in SGPRs that an asm statement loads and a LATER
+        # one waits for: a spill into VGPR lanes between the two copies stale values (it happened in a tuning
+        # variant: wrong results and a memory fault), besides putting v_writelane / v_readlane into the inner loop
+        if asm_async and re.match(r"^\s+(v_writelane|v_readlane)", line):
             bad.append((cur, "scalar register spill: " + line.strip()))
         if "s_endpgm" in line:
             cur = None
