@@ -269,6 +269,31 @@ def main():
         g = C.c_float()
         if L.glc_debug_clock_probe_end(enc._h, C.byref(g)) == 0 and 0.3 < g.value < 3.5:
             k1_clock_ghz = float(g.value)
+    # the same launches through the kernel this one replaced (k_mdct_fwd_dma, round 3's first half), pinned with
+    # glc_debug_set_mdct_variant: same process, same buffers, same probe - reported beside, never as `value`
+    k1_prev = None
+    if not args.lean and not dist_on:
+        L.glc_debug_set_mdct_variant.restype = C.c_int
+        L.glc_debug_set_mdct_variant.argtypes = [C.c_void_p, C.c_int]
+        if L.glc_debug_set_mdct_variant(enc._h, 1) == 0:
+            for _ in range(5):
+                k1()
+            pv_probe = L.glc_debug_clock_probe_begin(enc._h, int(0.6 * k1_reps * 580)) == 0
+            enc.timer_begin()
+            for _ in range(k1_reps):
+                k1()
+            pv_ms = enc.timer_end() / k1_reps
+            pv_ghz = None
+            if pv_probe:
+                g = C.c_float()
+                if L.glc_debug_clock_probe_end(enc._h, C.byref(g)) == 0 and 0.3 < g.value < 3.5:
+                    pv_ghz = float(g.value)
+            assert L.glc_debug_set_mdct_variant(enc._h, 0) == 0
+            k1_prev = {"kernel": "glc::k1::k_mdct_fwd_dma<4, 2, 1, false> (128x128 tile, both operands from LDS)",
+                       "ms_per_launch": round(pv_ms, 4), "clock_ghz_held": round(pv_ghz, 3) if pv_ghz else None,
+                       "shipped_over_previous": round(pv_ms / k1_ms, 4)}
+            for _ in range(5):
+                k1()
     enc.timer_begin()          # whole step with events too (profile cross-check)
     for _ in range(k1_reps):
         step()
@@ -493,10 +518,11 @@ def main():
                          "frac_at_held_clock": round(k1_tflops / k1_peak_held, 4) if k1_peak_held else None,
                          "frac_of_unfused_ceiling_at_held_clock": round(2.0 * k1_tflops / k1_peak_held, 4) if k1_peak_held else None,
                          "traffic": traffic, "traffic_source": traffic_source,
-                         "traffic_is": "bytes that missed the XCD L2s (FETCH_SIZE x 2 + WRITE_SIZE per launch, counters calibrated "
-                                       "on known byte counts); the 16 MiB working set of a step is Infinity-Cache resident, so "
-                                       "these are L2-fabric bytes, an upper bound on HBM bytes",
-                         "ms_per_launch": round(k1_ms, 4), "per_rank": k1_ranks,
+                         "traffic_is": "bytes that missed the XCD L2s (FETCH_SIZE / WRITE_SIZE per launch, each access pattern of the "
+                                       "kernel corrected by the factor measured for it on known byte counts: dwordx4 reads count "
+                                       "half, scalar loads and stores whole); the 16 MiB working set of a step is Infinity-Cache "
+                                       "resident, so these are L2-fabric bytes, an upper bound on HBM bytes",
+                         "ms_per_launch": round(k1_ms, 4), "per_rank": k1_ranks, "previous_kernel": k1_prev,
                          "note": "f32 vector-ALU issue roofline (157.3 TFLOP/s at 2.4 GHz counts an FMA as 2 flop); 4096 "
                                  "flop/sample = 2048 separately rounded mul + 2048 add.  Bit-exact parity forbids "
                                  "FMA and MFMA accumulation, so the ceiling of this kernel is 78.65 TFLOP/s "
