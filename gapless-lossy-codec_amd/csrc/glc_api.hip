@@ -422,7 +422,7 @@ int glc_ctx_tables(const glc_ctx *ctx, float *cos_table, float *window, float *n
 // alternate rounds on two streams)
 static int encode_range_on(glc_ctx *ctx, hipStream_t stream, DevBuf &coef_ws, const float *d_pcm, uint64_t t0, uint64_t t_count,
                            uint64_t n_samples, uint16_t channels, uint64_t frame_begin, uint64_t frame_end,
-                           void *d_records, float *d_coeffs, bool alternate_ok = false) {
+                           void *d_records, float *d_coeffs, bool alternate_ok = false, bool beside = false) {
   if (!ctx || !d_pcm || !d_records) return fail(ctx, GLC_EINVAL, "glc_encode_range_device: null argument");
   const glc_plan plan = glc::plan_encode(n_samples, channels);
   if (plan.n_frames == 0)
@@ -473,7 +473,7 @@ static int encode_range_on(glc_ctx *ctx, hipStream_t stream, DevBuf &coef_ws, co
     hipStream_t st = odd ? ctx->stream_b : stream;
     float *coef = d_coeffs ? d_coeffs + (f - frame_begin) * ch * glc::kHop : static_cast<float *>(odd ? ctx->coef_b.p : coef_ws.p);
     uint8_t *r = recs + (f - frame_begin) * rec;
-    GLC_HIP(ctx, glc::launch_mdct_forward(ctx->dev, view, f, M, coef, st, ctx->k1_variant));
+    GLC_HIP(ctx, glc::launch_mdct_forward(ctx->dev, view, f, M, coef, st, ctx->k1_variant, beside));
     bool decided = false;
     GLC_HIP(ctx, glc::launch_quantize(ctx->dev, coef, M, ch, view, f, r, st, &decided));
     if (!decided) GLC_HIP(ctx, glc::launch_decide_raw(ctx->dev, view, f, static_cast<uint32_t>(nf), r, st));
@@ -806,7 +806,7 @@ int glc_encode_hooked(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16
       hipError_t e = hipSuccess;
       uint8_t *recs = static_cast<uint8_t *>(ctx->records.p) + r.f0 * rec;
       int rc = encode_range_on(ctx, cs, (i & 1) ? ctx->coef_b : ctx->coef, d_pcm, 0, t_count, n_samples, channels, r.f0,
-                               r.f0 + r.nf, recs, nullptr);
+                               r.f0 + r.nf, recs, nullptr, /*alternate_ok=*/false, /*beside=*/true);
       if (rc != GLC_OK) return prog.set_error(rc, my_err);
       e = hipEventRecord(ev_rec[i], cs);
       if (e != hipSuccess) return prog.set_error(GLC_EHIP, hip_msg("glc_encode: queueing a round", e));
@@ -1398,7 +1398,7 @@ int glc_debug_set_imdct_variant(glc_ctx *ctx, int variant) {
 }
 
 int glc_debug_set_mdct_variant(glc_ctx *ctx, int variant) {
-  if (!ctx || variant < 0 || variant > 3) return fail(ctx, GLC_EINVAL, "glc_debug_set_mdct_variant: variant must be 0..3");
+  if (!ctx || variant < 0 || variant > 4) return fail(ctx, GLC_EINVAL, "glc_debug_set_mdct_variant: variant must be 0..4");
   ctx->k1_variant = variant;
   return GLC_OK;
 }

@@ -31,7 +31,7 @@ struct PcmView {
 
 // K1: windowed forward MDCT of rows [0, M) (row = (frame - frame_begin)*ch + c) -> coef[M][1024].
 hipError_t launch_mdct_forward(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin,
-                               uint32_t M, float *coef, hipStream_t s, int variant = 0);
+                               uint32_t M, float *coef, hipStream_t s, int variant = 0, bool beside = false);
 // K2: scale, masking thresholds, quantiser -> record header {scale,nnz} + dense i16 row.  For 1 / 2 /
 // 4 channels the kernel also takes the raw-vs-compressed decision and writes the raw plane of raw
 // frames (*decided = true: do not launch K3); `pcm` / `frame_begin` are what that needs.

@@ -1037,7 +1037,7 @@ hipError_t launch_dma_ch(const DeviceTables &t, const PcmView &pcm, uint64_t fra
 }  // namespace
 
 hipError_t launch_mdct_forward(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin,
-                               uint32_t M, float *coef, hipStream_t s, int variant) {
+                               uint32_t M, float *coef, hipStream_t s, int variant, bool beside) {
   // Shapes measured with tools/k1_tune.hip.  The f32 VALU needs >= 4 waves per SIMD to approach its
   // issue rate, so every kernel for 4096 rows or more keeps 4 x 8 outputs per lane (32 accumulators) and
   // 16 waves per CU.
@@ -1047,10 +1047,16 @@ hipError_t launch_mdct_forward(const DeviceTables &t, const PcmView &pcm, uint64
   // kernels (profiles/r03_k1_tune_short_clips.txt, r03_k1_tune_mid_sizes.txt): 172 rows 0.053-0.058 ms (4 x 8
   // tile: 0.19), 600 rows 0.10, 1024 rows 0.11, 2048 rows 0.20, 3072 rows 0.28; a launch of 256-row tiles costs
   // 0.28-0.34 ms however few rows it has (one workgroup's chain) and draws level at about 3500 rows - when
-  // the channel count has a segment loader; with one dword per (row, sample) only at 4096.  (Rounds 1-3 kept a
-  // 64 x 128 kernel for 1793..4095 rows: 0.22 ms at 2048 rows, 0.34 at 3072 - slower than both neighbours.)
+  // the channel count has a segment loader; with one dword per (row, sample) only at 4096.  (Rounds 1-3 used a
+  // 64 x 128 kernel for 1793..4095 rows: 0.22 ms at 2048 rows, 0.34 at 3072 - slower than both neighbours when
+  // a launch has the chip to itself; it keeps one job, below.)
   const bool seg = pcm.ch == 1 || pcm.ch == 2 || pcm.ch == 4 || pcm.ch == 8;
   if (M <= 640) return k1::launch_small<2>(t, pcm, frame_begin, M, coef, s);
+  // beside: an opening round of glc_encode (2048 rows), which runs beside its neighbours' kernels on a second
+  // stream.  Alone the 2 x 4 kernel is faster there (0.198 against 0.221 ms), but its 1024 workgroups fill every
+  // CU four deep and two such launches get in each other's way; the 64 x 128 kernel of rounds 1-3 puts ONE
+  // workgroup on each CU: glc_encode at config 2 1.00-1.02 ms against 1.05-1.08 (profiles/r03_encode_rounds_kernel.txt).
+  if ((beside || variant == 4) && M > 1792 && M <= 2048) return k1::launch_sched<64, 128, 16, 4>(t, pcm, frame_begin, M, coef, s);
   if (M < (seg ? 3584u : 4096u)) return k1::launch_small<4>(t, pcm, frame_begin, M, coef, s);
   // variant (include/glc_debug.h glc_debug_set_mdct_variant): 0 = shipped, 1 = round 3's kernel, 2 / 3 = one form for every launch
   if (variant == 1) return launch_dma_ch(t, pcm, frame_begin, M, coef, s);

@@ -22,6 +22,10 @@
 //                      glc_debug_set_mdct_variant(ctx, 1): 128x128 tile, 512 threads, 4x8 outputs per lane
 //                      with lanes <-> columns, both operands from LDS (table tile by LDS-DMA two stages
 //                      ahead); 8-9 % slower on real samples because the chip holds less clock under it.
+//   k_mdct_fwd_sched   the opening rounds of glc_encode (2048 rows each, running beside each other), as <64,128,16,4>:
+//                      64x128 tile, 256 threads, ONE workgroup per CU; hand-scheduled inline-asm i-steps (step4), LDS
+//                      operand prefetch, XCD-aware tile map, register staging, classic double buffer.  (Rounds 1-3:
+//                      every launch of 1793..4095 rows.)
 //   k_mdct_fwd_small   below 3584 rows (4096 for channel counts without a segment loader): 2x2 / 2x4 outputs per
 //                      lane (<= 640 rows / above) on 32x32 / 32x64 tiles, 256 threads,
 //                      hand-scheduled with a register ring of LDS operands and counted lgkmcnt waits
@@ -373,6 +377,151 @@ __device__ __forceinline__ void step4(f32x2 (&acc)[4][4], const Operands &c, Ope
           [t6] "=&v"(t6), [t7] "=&v"(t7)
         : [ca0] "v"(c.a0), [ca1] "v"(c.a1), [cb0] "v"(c.b0), [cb1] "v"(c.b1), [cb2] "v"(c.b2), [cb3] "v"(c.b3));
   }
+}
+
+// 64x128 (BM x BN) tile, 4x8 outputs per lane, register staging, two LDS slots per operand tile.
+template <int BM, int BN, int BK, int MINW>
+__global__ __launch_bounds__((BM / 4) * (BN / 8)) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
+void k_mdct_fwd_sched(DeviceTables tb, PcmView pcm, long long frame_begin, unsigned M,
+                      float *__restrict__ coef) {
+  constexpr int TM = 4;
+  using C = Cfg<BM, BN, BK, TM, 8, 2, MINW>;
+  __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+
+  const int tid = threadIdx.x;
+  // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 says which blocks share an
+  // L2).  Give XCD x the contiguous tile range [x*T/8, (x+1)*T/8) in (m_tile, n_tile) order: the
+  // PCM rows of an m-tile are then fetched by ONE XCD instead of all eight, and the table rows of
+  // a stage are shared in that XCD's L2 by all resident m-tiles, which sweep i together
+  // (measured: 4x less L2 fill traffic).  Placement affects speed only, never results.
+  static_assert(C::kNTiles == 8, "tile map assumes 8 coefficient tiles");
+  const unsigned g = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int n_tile = g % C::kNTiles;
+  const int m_tile = g / C::kNTiles;
+  const int m0 = m_tile * BM;
+  const int n0 = n_tile * BN;
+  const int tx = tid % C::kNtx, ty = tid / C::kNtx;
+
+  const long long ch = pcm.ch;
+  const long long f0 = frame_begin + m0 / pcm.ch;
+  const long long e_first = (f0 * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * ch;
+  long long e_end = static_cast<long long>(pcm.t_count) * ch;
+  const long long n_rel = static_cast<long long>(pcm.n_samples) - static_cast<long long>(pcm.t0) * ch;
+  if (e_end > n_rel) e_end = n_rel;
+  const long long e_base = e_first < 0 ? 0 : e_first;
+  long long e_cnt = e_end - e_base;
+  if (e_cnt < 0) e_cnt = 0;
+  if (e_cnt > (1ll << 28)) e_cnt = 1ll << 28;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(pcm.p + e_base), 0, static_cast<int>(e_cnt * 4), 0x00020000);
+
+  const int a_r = tid % BM;
+  const int a_i = tid / BM;
+  const unsigned a_row = m0 + a_r;
+  unsigned a_off = 0x80000000u;
+  if (a_row < M) {
+    const long long f = frame_begin + a_row / pcm.ch;
+    const long long c = a_row % pcm.ch;
+    const long long e_row = (f * kHopI - kHopI / 2 - static_cast<long long>(pcm.t0)) * ch + c;
+    a_off = static_cast<unsigned>((e_row - e_base + a_i * ch) * 4);
+  }
+  const unsigned a_step = static_cast<unsigned>(C::kAStride * ch * 4);
+  const float *w_ptr = tb.window + a_i;
+  const int b_r = tid / (BN / 4), b_c4 = tid % (BN / 4);
+  const float *b_ptr = tb.cos_t + n0 + static_cast<size_t>(b_r) * kHopI + b_c4 * 4;
+
+  // staging registers: raw sample and window value are multiplied only when the stage is
+  // written to LDS, so the wave waits for its global loads at the END of the stage
+  float a_raw[C::kAPer], a_win[C::kAPer];
+  f32x4 b_stage[C::kBPer];
+  auto load_stage = [&](int i0) {
+    const unsigned off0 = a_off + static_cast<unsigned>(i0) * static_cast<unsigned>(ch * 4);
+#pragma unroll
+    for (int j = 0; j < C::kAPer; ++j) {
+      a_raw[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(a_rsrc, off0 + j * a_step, 0, 0));
+      a_win[j] = w_ptr[i0 + C::kAStride * j];
+    }
+#pragma unroll
+    for (int j = 0; j < C::kBPer; ++j)
+      b_stage[j] = *reinterpret_cast<const f32x4 *>(b_ptr + static_cast<size_t>(i0 + C::kBRowsPer * j) * kHopI);
+  };
+  auto store_stage = [&](int buf) {
+    // pin the first use of the staged registers behind the stage's math (volatile asm
+    // statements keep their order): hipcc otherwise hoists the multiply, and with it the
+    // vmcnt wait, into the middle of the stage
+#pragma unroll
+    for (int j = 0; j < C::kAPer; ++j) {
+      float r = a_raw[j], w = a_win[j];
+      asm volatile("" : "+v"(r), "+v"(w));
+      As[buf][(a_i + C::kAStride * j) * BM + a_r] = mul_rn(r, w);  // block[i] = slice[i]*window[i], :480
+    }
+#pragma unroll
+    for (int j = 0; j < C::kBPer; ++j) {
+      f32x4 b = b_stage[j];
+      asm volatile("" : "+v"(b));
+      *reinterpret_cast<f32x4 *>(&Bs[buf][(b_r + C::kBRowsPer * j) * BN + b_c4 * 4]) = b;
+    }
+  };
+
+  f32x2 acc[TM][4];
+#pragma unroll
+  for (int r = 0; r < TM; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = f32x2{0.0f, 0.0f};
+
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+
+  // LDS byte addresses of this lane's operand columns (low 32 bits of a generic LDS pointer)
+  const unsigned a_lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(&As[0][ty * 4]));
+  const unsigned b_lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(&Bs[0][tx * 4]));
+
+  constexpr int kStages = kFrameI / BK;
+#pragma unroll 1
+  for (int s = 0; s < kStages; ++s) {
+    const int buf = s & 1;
+    load_stage(((s + 1) & (kStages - 1)) * BK);
+    const unsigned a_addr = a_lds0 + buf * (BK * BM * 4);
+    const unsigned b_addr = b_lds0 + buf * (BK * BN * 4);
+    Operands X, Y;
+    lds_fetch4<BM, BN>(X, a_addr, b_addr, 0);
+    lds_wait4(X);
+#pragma unroll
+    for (int ii = 0; ii < BK; ii += 2) {
+      step4<BM, BN, true>(acc, X, Y, a_addr, b_addr, ii + 1);
+      if (ii + 2 < BK) step4<BM, BN, true>(acc, Y, X, a_addr, b_addr, ii + 2);
+      else step4<BM, BN, false>(acc, Y, X, a_addr, b_addr, 0);
+    }
+    store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int r = 0; r < TM; ++r) {
+    const unsigned row = m0 + ty * 4 + r;
+    if (row >= M) continue;
+    float *dst = coef + static_cast<size_t>(row) * kHopI + n0;
+    float4 o;
+    o.x = mul_rn(acc[r][0].x, tb.norm); o.y = mul_rn(acc[r][0].y, tb.norm);
+    o.z = mul_rn(acc[r][1].x, tb.norm); o.w = mul_rn(acc[r][1].y, tb.norm);
+    *reinterpret_cast<float4 *>(dst + tx * 4) = o;
+    o.x = mul_rn(acc[r][2].x, tb.norm); o.y = mul_rn(acc[r][2].y, tb.norm);
+    o.z = mul_rn(acc[r][3].x, tb.norm); o.w = mul_rn(acc[r][3].y, tb.norm);
+    *reinterpret_cast<float4 *>(dst + BN / 2 + tx * 4) = o;
+  }
+}
+
+template <int BM, int BN, int BK, int MINW>
+inline hipError_t launch_sched(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M,
+                               float *coef, hipStream_t s) {
+  using C = Cfg<BM, BN, BK, 4, 8, 2, MINW>;
+  if (M == 0) return hipSuccess;
+  const unsigned m_tiles = (M + BM - 1) / BM;
+  hipLaunchKernelGGL((k_mdct_fwd_sched<BM, BN, BK, MINW>), dim3(m_tiles * C::kNTiles), dim3(C::kThreads), 0, s, t, pcm,
+                     static_cast<long long>(frame_begin), M, coef);
+  return hipGetLastError();
 }
 
 #ifndef GLC_K1_A_STRIDE

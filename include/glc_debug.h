@@ -34,6 +34,8 @@ int glc_debug_set_imdct_variant(glc_ctx *ctx, int variant);
  *   1  k_mdct_fwd_dma: round 3's kernel (128 x 128 tile, both operands from LDS)
  *   2  k_mdct_fwd_st, 8 waves per workgroup for every launch
  *   3  k_mdct_fwd_st, 16 waves per workgroup for every launch
+ *   4  shipped, and launches of 1793..2048 rows take k_mdct_fwd_sched (64 x 128 tile) - the kernel glc_encode gives
+ *      its opening rounds, which run beside each other; a launch that has the chip to itself takes the 2 x 4 kernel
  * All of them produce the same bits (tests/test_gpu_parity.py). */
 int glc_debug_set_mdct_variant(glc_ctx *ctx, int variant);
 

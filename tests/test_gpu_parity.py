@@ -791,6 +791,31 @@ def test_k1_large_launch_coefficient_bits(torch_cuda, ch, kernel):
         launch_and_check(f0, f0 * 1024 - 512, L - (f0 * 1024 - 512), [f0, nf // 2 - 1, nf - W])
 
 
+def test_k1_round_kernel_of_the_host_pipeline(torch_cuda):
+    """The kernel glc_encode gives its opening rounds (k_mdct_fwd_sched: launches of 1793..2048 rows that run
+    beside each other), pinned through include/glc_debug.h variant 4: every coefficient word of a 2048-row
+    and of a ragged 1800-row launch equals the 2 x 4 kernel's, windows of it equal the oracle's."""
+    for ch, frames in ((2, 1024), (1, 2048), (4, 450), (3, 640)):
+        x, sr = _k1_stream(ch, frames, 900 + ch)
+        plan = glc_amd.plan_encode(x.size, ch)
+        nf = plan.n_frames
+        assert 1792 < nf * ch <= 2048
+        d_pcm = torch_cuda.from_numpy(x).cuda()
+        enc = glc_amd.Encoder(sr)
+        out = []
+        for variant in (4, 0):
+            _set_mdct_variant(enc, variant)
+            d_coef = torch_cuda.full((nf * ch, 1024), float("nan"), dtype=torch_cuda.float32, device="cuda")
+            torch_cuda.cuda.synchronize()
+            enc.mdct_forward_device(d_pcm.data_ptr(), 0, plan.per_channel, x.size, ch, 0, nf, d_coef.data_ptr())
+            enc.synchronize()
+            out.append(d_coef.cpu().numpy())
+        assert np.array_equal(bits(out[0]), bits(out[1]))
+        for a in (0, nf // 2, nf - 4):
+            _, ref = O.encode_range_records(x, 0, plan.per_channel, x.size, sr, ch, a, a + 4, taps=True)
+            assert np.array_equal(bits(out[0][a * ch:(a + 4) * ch]), bits(ref.coeffs))
+
+
 def test_k1_small_launch_tile_edges(torch_cuda):
     """The short-clip transform (k_mdct_fwd_small: 2 x 2 outputs per lane up to 640 rows, 2 x 4 above)
     across its 32-row tile edges, with partial last tiles, ragged ends, and at both ends of each range

@@ -2,7 +2,7 @@
 multiply-add (v_fma*, v_fmac*, v_pk_fma*, v_mad*, v_mac*, v_dot*) or an accumulating MFMA — the
 reference accumulates with a separately rounded multiply and add.
 
-  k_mdct_fwd_dma / k_mdct_fwd_st / k_mdct_fwd_small / k_imdct_apply  strict: no fused op at all (no division or sqrt inside)
+  k_mdct_fwd_sched / k_mdct_fwd_dma / k_mdct_fwd_st / k_mdct_fwd_small / k_imdct_apply  strict: no fused op at all (no division or sqrt inside)
   k_imdct_rows / k_imdct_plan   fused ops allowed only inside hipcc's correctly-rounded f32 division expansion
                 (v_div_scale ... v_div_fixup), which the raw-frame path `i16 / 32767.0` needs
 The quantiser / decision / overlap-add kernels are not scanned: their IEEE divide, sqrt and
@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "gapless-lossy-codec_amd", "csrc")
 ISA = os.path.join(ROOT, "build", "isa", "glc_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")
 FORBIDDEN = re.compile(r"^\s+(v_fma\w*|v_fmac\w*|v_pk_fma\w*|v_mad_\w*f32|v_mac\w*|v_dot\w*|v_mfma\w*)\b")
-KERNELS = ("k_mdct_fwd_dma", "k_mdct_fwd_st", "k_mdct_fwd_small", "k_imdct_rows", "k_imdct_plan", "k_imdct_apply")
+KERNELS = ("k_mdct_fwd_sched", "k_mdct_fwd_dma", "k_mdct_fwd_st", "k_mdct_fwd_small", "k_imdct_rows", "k_imdct_plan", "k_imdct_apply")
 DIV_WINDOW = {"k_imdct_rows", "k_imdct_plan"}
 
 

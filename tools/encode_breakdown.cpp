@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "glc.h"
+#include "glc_debug.h"
 
 #define OK(x)                                                            \
   do {                                                                   \
@@ -56,6 +57,10 @@ int main(int argc, char **argv) {
   std::printf("input: %s\n", from_file ? "build/chord_cfg2.f32 (the bench's batch)" : "stand-in chord");
   glc_ctx *ctx = nullptr;
   GL(glc_ctx_create(0, 48000, &ctx));
+  if (const char *v = std::getenv("GLC_MDCT_VARIANT")) {  // include/glc_debug.h: which forward-transform kernel (A / B runs)
+    GL(glc_debug_set_mdct_variant(ctx, std::atoi(v)));
+    std::printf("forward-transform variant %s\n", v);
+  }
   hipStream_t s = static_cast<hipStream_t>(glc_ctx_stream(ctx));
   glc_plan plan;
   GL(glc_plan_encode(n, ch, &plan));

@@ -160,6 +160,7 @@ int main(int argc, char **argv) {
       // 4096 rows the short-clip / 64 x 128 kernels the library would take for that row count
       hipError_t launched;
       if (M <= 640) launched = k1::launch_small<2>(tb, pcm, 0, M, d_out, 0);
+      else if (M > 1792 && M <= 2048 && (r & 1)) launched = k1::launch_sched<64, 128, 16, 4>(tb, pcm, 0, M, d_out, 0);  // glc_encode's opening rounds
       else if (M < 3584 || (M < 4096 && (r & 4))) launched = k1::launch_small<4>(tb, pcm, 0, M, d_out, 0);
       else {
         const bool seg = (r & 2) == 0 && (ch == 1 || ch == 2 || ch == 4 || ch == 8);
@@ -264,7 +265,7 @@ int main(int argc, char **argv) {
       Variant{"[row] C=8 bk32, per-row loader", k1::launch_row<8, 0, 32>},
       Variant{"[row] SHIPPED small 2x2 (<= 640 rows)", k1::launch_small<2>},
       Variant{"[row] SHIPPED small 2x4 (641..3583 rows)", k1::launch_small<4>},
-      Variant{"[row] sched 64x128 (shipped for 1793..4095 rows until round 3)", k1x::launch_sched<64, 128, 16, 4, 0, 4>},
+      Variant{"[row] SHIPPED sched 64x128 (the opening rounds of glc_encode; 1793..4095 rows until round 3)", k1::launch_sched<64, 128, 16, 4>},
       Variant{"[row] st 8 waves (>= 4096 rows)", k1::launch_st<4, 2, 1, 4>},
       // k_mdct_fwd_st: the table from SGPRs, lanes <-> rows (K1_FILTER='[cand]' K1_ROUNDS=4 compares interleaved)
       Variant{"[cand] dma 128x128 PRIO 1 (shipped until round 3), the channel count's own loader",
@@ -315,7 +316,7 @@ int main(int argc, char **argv) {
       Variant{"[abl] st 8 waves bk16 d4 PRIO 1: table address does not advance", k1::launch_st<4, 2, 1, 4, 8, 16, 1>},
       Variant{"[abl] st 8 waves bk16 d4 PRIO 1: no staging, no barrier", k1::launch_st<4, 2, 1, 4, 8, 16, 2>},
       Variant{"[abl] st 8 waves bk16 d4 PRIO 1: neither", k1::launch_st<4, 2, 1, 4, 8, 16, 3>},
-      Variant{"sched 64x128 256thr (shipped for 1793..4095 rows until round 3)", k1x::launch_sched<64, 128, 16, 4, 0, 4>},
+      Variant{"SHIPPED sched 64x128 256thr (the opening rounds of glc_encode; 1793..4095 rows until round 3)", k1::launch_sched<64, 128, 16, 4>},
       Variant{"SHIPPED small 32x32 t2x2 256thr, hand-scheduled (<= 640 rows)", k1::launch_small<2>},
       Variant{"SHIPPED small 32x64 t2x4 256thr, hand-scheduled (641..3583 rows)", k1::launch_small<4>},
       Variant{"round 2: hipcc-scheduled 32x64 t4x4 (was shipped for <= 512 rows)", k1::launch<32, 64, 32, 4, 4, 4, 2>},
