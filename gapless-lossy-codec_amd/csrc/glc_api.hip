@@ -673,7 +673,8 @@ int glc_encode_hooked(glc_ctx *ctx, const float *pcm, uint64_t n_samples, uint16
   // launches: 0.87 ms on one stream, 0.67 ms alternating, 0.59 ms as one launch; two 2048-frame ones
   // 0.66 / 0.60).  BASELINE config 2 (4096 stereo frames) is the four opening rounds; a stream of
   // one round runs on this thread alone.
-  const uint64_t piece = std::max<uint64_t>(1, (2048 + ch - 1) / ch);  // frames of an opening round
+  // (at most 2048 rows: the size the round kernel of launch_mdct_forward - `beside` - is dealt one workgroup per CU for)
+  const uint64_t piece = std::max<uint64_t>(1, 2048 / ch);  // frames of an opening round
   const uint64_t opening = 4 * piece;
   struct Round {
     uint64_t f0, nf, blob_off, hi;  // hi: interleaved samples that must be on the device before its kernels run
