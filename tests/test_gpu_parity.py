@@ -1061,7 +1061,7 @@ def test_host_encode_pipeline_across_density_changes(torch_cuda, ch, shape):
     pool) must give exactly the bytes of the unpipelined device path - one frames_from_device_records over
     the whole range - and, on windows across round boundaries, the oracle's records."""
     sr = 48000
-    piece = (2048 + ch - 1) // ch            # frames of an opening round; four of them, then 4096 (csrc/glc_api.hip)
+    piece = max(1, 2048 // ch)               # frames of an opening round; four of them, then 4096 (csrc/glc_api.hip)
     first = 4 * piece
     rounds = 3 if shape.startswith("three") else 2
     nf = first + 4096 * (rounds - 1) - 37    # ragged last round
@@ -1149,7 +1149,7 @@ def test_pipelined_encode_contexts_come_and_go_and_run_side_by_side(torch_cuda):
     sr = 48000
     streams = []
     for i, ch in enumerate((2, 5, 1)):
-        piece = (2048 + ch - 1) // ch
+        piece = max(1, 2048 // ch)
         nf = 4 * piece + 4096 + 300 + 17 * i   # four opening rounds, one full round, a ragged one
         rng = np.random.default_rng(500 + i)
         t = np.arange(nf * 1024, dtype=np.float64)[:, None]

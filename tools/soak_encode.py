@@ -26,7 +26,7 @@ for case in range(cases):
     sr = int(rng.choice(rates))
     ch = int(rng.choice([1, 1, 2, 2, 2, 3, 4, 5, 6, 8]))
     n_per = int(rng.integers(513, 30000)) if rng.random() < 0.9 else int(rng.integers(30000, 600000))
-    if pipeline:  # first round = ceil(4096 / ch) frames, later rounds 4096: 2 .. 4 rounds
+    if pipeline:  # opening rounds of 2048 // ch frames, later rounds 4096: 2 .. 4 rounds
         ch = int(rng.choice([8, 12, 16, 24]))
         first = -(-4096 // ch)
         frames = 2 * first + int(rng.integers(1, 300)) if rng.random() < 0.8 else first + 4096 + int(rng.integers(1, 600))
