@@ -243,6 +243,7 @@ def test_stream_id_keeps_rows_and_plan_resident(torch_cuda):
     blocks_ref = None
     for i in range(3):
         d_blk = torch.full((nf * ch, 2048), float("nan"), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()  # the fill runs on torch's stream, the decoder on its own: without this the NaNs can land last
         dec.imdct_device(b, 0, nf, d_blk.data_ptr())
         dec.synchronize()
         h = d_blk.cpu().numpy()
