@@ -79,7 +79,10 @@ int glc_ctx_create(int device, uint32_t sample_rate, glc_ctx **out);
 void glc_ctx_destroy(glc_ctx *ctx);
 /* Message of the last failure on `ctx` (or of the last context-less failure if ctx == NULL). */
 const char *glc_last_error(const glc_ctx *ctx);
-/* The HIP stream (hipStream_t) every kernel of this context is launched on. */
+/* The HIP stream (hipStream_t) every kernel of this context is launched on.  It is a stream of the context's own,
+ * created non-blocking: it does NOT wait for work a caller has queued elsewhere (not even on the legacy default
+ * stream).  A device buffer that another stream is still filling or reading must be synchronised with by the
+ * caller - or the context put on that stream with glc_ctx_set_stream - before an entry point is given it. */
 void *glc_ctx_stream(glc_ctx *ctx);
 int glc_ctx_device(const glc_ctx *ctx);
 /* Run this context's kernels on a caller-owned hipStream_t instead (e.g. the stream a host
