@@ -996,9 +996,6 @@ hipError_t launch_clock_probe(uint64_t ticks_100mhz, uint64_t *out, hipStream_t 
   return hipGetLastError();
 }
 
-namespace {
-}  // namespace
-
 // ---------------------------------------------------------------------------- launchers
 
 // Which kernel takes a launch of 3584 / 4096 rows or more (the rest of the dispatch is by row count alone):
