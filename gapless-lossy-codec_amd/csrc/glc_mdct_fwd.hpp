@@ -885,9 +885,14 @@ __device__ __forceinline__ void st_mac(f32x2 (&acc)[4][4], const StOps<D> &o) {
 // PRIO 1: priority by quarter of the i loop (between the two workgroups of a CU, as k_mdct_fwd_dma);
 // PRIO 2: by distance from the last barrier (inside a workgroup: whoever is behind goes first).
 // ABL (tuning only, wrong results): 1 = the table address does not advance, 2 = no staging and no barrier.
-template <int MINW, int CH = 0, int PRIO = 0, int D = 2, int NW = 8, int BK = 16, int ABL = 0>
+// STAMP (tuning only): workgroup timeline into `stamps` - entry, loop start, the quarter points, loop end, stores drained.
+template <int MINW, int CH = 0, int PRIO = 0, int D = 2, int NW = 8, int BK = 16, int ABL = 0, bool STAMP = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(MINW, MINW)))
-void k_mdct_fwd_st(DeviceTables tb, PcmView pcm, long long frame_begin, unsigned M, float *__restrict__ coef) {
+void k_mdct_fwd_st(DeviceTables tb, PcmView pcm, long long frame_begin, unsigned M, float *__restrict__ coef,
+                   unsigned long long *__restrict__ stamps) {
+  if constexpr (STAMP) {
+    if (threadIdx.x == 0) stamps[static_cast<size_t>(blockIdx.x) * 8] = __builtin_amdgcn_s_memrealtime();
+  }
   // CH as in k_mdct_fwd_dma: 0 = one PCM dword per (row, i) and lane; 1 / 2 / 4 / 8 = the stream's
   // channel count, BK samples x CH channels of a frame fetched as BK / 4 * CH dwordx4.
   constexpr int BM = 256, BN = 8 * NW, RING = 3;
@@ -1050,9 +1055,15 @@ void k_mdct_fwd_st(DeviceTables tb, PcmView pcm, long long frame_begin, unsigned
   StOps<D> X, Y;
   st_fetch<0, kAS>(X, a_lds0, b_base);
   st_wait(X);
+  if constexpr (STAMP) {
+    if (tid == 0) stamps[static_cast<size_t>(blockIdx.x) * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+  }
   if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(3);
 #pragma unroll 1
   for (int s = 0; s < kStages; ++s) {
+    if constexpr (STAMP) {
+      if (tid == 0 && s && s % (kStages / 4) == 0) stamps[static_cast<size_t>(blockIdx.x) * 8 + 1 + s / (kStages / 4)] = __builtin_amdgcn_s_memrealtime();
+    }
     if constexpr (PRIO == 1) {
       constexpr int kQuarter = kStages / 4;
       if (s % kQuarter == 0) {
@@ -1115,6 +1126,9 @@ void k_mdct_fwd_st(DeviceTables tb, PcmView pcm, long long frame_begin, unsigned
 #undef GLC_ST_HANDOFF
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the wrap-around prefetch
+  if constexpr (STAMP) {
+    if (tid == 0) stamps[static_cast<size_t>(blockIdx.x) * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+  }
 
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -1129,16 +1143,21 @@ void k_mdct_fwd_st(DeviceTables tb, PcmView pcm, long long frame_begin, unsigned
     o.z = mul_rn(acc[r][3].x, tb.norm); o.w = mul_rn(acc[r][3].y, tb.norm);
     *reinterpret_cast<float4 *>(dst + 4) = o;
   }
+  if constexpr (STAMP) {  // this wave's stores have left the CU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) stamps[static_cast<size_t>(blockIdx.x) * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
-template <int MINW, int CH = 0, int PRIO = 0, int D = 2, int NW = 8, int BK = 16, int ABL = 0>
+template <int MINW, int CH = 0, int PRIO = 0, int D = 2, int NW = 8, int BK = 16, int ABL = 0, bool STAMP = false>
 inline hipError_t launch_st(const DeviceTables &t, const PcmView &pcm, uint64_t frame_begin, uint32_t M, float *coef,
-                            hipStream_t s) {
+                            hipStream_t s, unsigned long long *stamps = nullptr) {
   if (M == 0) return hipSuccess;
   if (CH != 0 && pcm.ch != static_cast<uint32_t>(CH)) return hipErrorInvalidValue;
+  if (STAMP && !stamps) return hipErrorInvalidValue;
   const unsigned m_tiles = (M + 255) / 256;
-  hipLaunchKernelGGL((k_mdct_fwd_st<MINW, CH, PRIO, D, NW, BK, ABL>), dim3(m_tiles * (kHopI / (8 * NW))), dim3(NW * 64), 0,
-                     s, t, pcm, static_cast<long long>(frame_begin), M, coef);
+  hipLaunchKernelGGL((k_mdct_fwd_st<MINW, CH, PRIO, D, NW, BK, ABL, STAMP>), dim3(m_tiles * (kHopI / (8 * NW))), dim3(NW * 64), 0,
+                     s, t, pcm, static_cast<long long>(frame_begin), M, coef, stamps);
   return hipGetLastError();
 }
 

@@ -58,6 +58,11 @@ template <int MINW, int CH, int PRIO>
 static hipError_t dma_prio(const DeviceTables &t, const PcmView &pcm, uint64_t f0, uint32_t M, float *coef, hipStream_t s) {
   return k1::launch_dma<MINW, CH, PRIO>(t, pcm, f0, M, coef, s);
 }
+// ... and launch_st
+template <int... Ps>
+static hipError_t st_v(const DeviceTables &t, const PcmView &pcm, uint64_t f0, uint32_t M, float *coef, hipStream_t s) {
+  return k1::launch_st<Ps...>(t, pcm, f0, M, coef, s);
+}
 template <int MINW, int CH = 0>
 static hipError_t dma_shipped(const DeviceTables &t, const PcmView &pcm, uint64_t f0, uint32_t M, float *coef, hipStream_t s) {
   return k1::launch_dma<MINW, CH>(t, pcm, f0, M, coef, s);
@@ -221,9 +226,46 @@ int main(int argc, char **argv) {
       }
       fflush(stdout);
     };
-    show("PRIO 0 (shipped)", [&] { return k1::launch_dma<4, 2, 0, true>(tb, pcm, 0, M, d_out, 0, d_st); });
-    show("PRIO 1 (by quarter)", [&] { return k1::launch_dma<4, 2, 1, true>(tb, pcm, 0, M, d_out, 0, d_st); });
-    show("PRIO 3 (cycle of 16 stages)", [&] { return k1::launch_dma<4, 2, 3, true>(tb, pcm, 0, M, d_out, 0, d_st); });
+    // k_mdct_fwd_st stamps: 0 entry, 1 loop start, 2..4 quarter points, 5 loop end, 6 stores drained
+    auto show_st = [&](const char *name, unsigned n_st, auto launch) {
+      for (int i = 0; i < 200; ++i) CHECK(launch());  // warm clocks; the stamps kept are those of the LAST launch
+      CHECK(hipDeviceSynchronize());
+      CHECK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+      unsigned long long t0 = ~0ull;
+      for (unsigned b = 0; b < n_st; ++b) t0 = std::min(t0, st[size_t(b) * 8]);
+      printf("%s (%u workgroups; microseconds after the first workgroup's first instruction)\n", name, n_st);
+      static const char *what[7] = {"entry", "loop start", "1/4 of loop", "1/2 of loop", "3/4 of loop", "loop end", "stores drained"};
+      for (int q = 0; q <= 6; ++q) {
+        std::vector<double> a;
+        for (unsigned b = 0; b < n_st; ++b) a.push_back((st[size_t(b) * 8 + q] - t0) * 0.01);
+        std::sort(a.begin(), a.end());
+        printf("  %-15s us: min %7.1f p10 %7.1f p50 %7.1f p90 %7.1f max %7.1f\n", what[q], a.front(), a[a.size() / 10],
+               a[a.size() / 2], a[a.size() * 9 / 10], a.back());
+      }
+      // the dispatcher deals consecutive workgroups round-robin over the 8 XCDs: loop end by XCD
+      printf("  loop end by XCD (mean / max us):");
+      for (unsigned x = 0; x < 8; ++x) {
+        double sum = 0, mx = 0;
+        unsigned n = 0;
+        for (unsigned b = x; b < n_st; b += 8, ++n) {
+          const double v = (st[size_t(b) * 8 + 5] - t0) * 0.01;
+          sum += v;
+          mx = std::max(mx, v);
+        }
+        printf("  %u: %.1f / %.1f", x, sum / n, mx);
+      }
+      printf("\n");
+      fflush(stdout);
+    };
+    show_st("k_mdct_fwd_st, 16 waves per workgroup, PRIO 2 (shipped at config 2)", (M + 255) / 256 * 8,
+            [&] { return k1::launch_st<4, 2, 2, 4, 16, 16, 0, true>(tb, pcm, 0, M, d_out, 0, d_st); });
+    show_st("k_mdct_fwd_st, 8 waves per workgroup, PRIO 1", (M + 255) / 256 * 16,
+            [&] { return k1::launch_st<4, 2, 1, 4, 8, 16, 0, true>(tb, pcm, 0, M, d_out, 0, d_st); });
+    show_st("k_mdct_fwd_st, 16 waves per workgroup, PRIO 2 (again)", (M + 255) / 256 * 8,
+            [&] { return k1::launch_st<4, 2, 2, 4, 16, 16, 0, true>(tb, pcm, 0, M, d_out, 0, d_st); });
+    show("k_mdct_fwd_dma PRIO 0 (round 2)", [&] { return k1::launch_dma<4, 2, 0, true>(tb, pcm, 0, M, d_out, 0, d_st); });
+    show("k_mdct_fwd_dma PRIO 1 (by quarter; round 3, first half)", [&] { return k1::launch_dma<4, 2, 1, true>(tb, pcm, 0, M, d_out, 0, d_st); });
+    show("k_mdct_fwd_dma PRIO 3 (cycle of 16 stages)", [&] { return k1::launch_dma<4, 2, 3, true>(tb, pcm, 0, M, d_out, 0, d_st); });
     return 0;
   }
 
@@ -266,7 +308,7 @@ int main(int argc, char **argv) {
       Variant{"[row] SHIPPED small 2x2 (<= 640 rows)", k1::launch_small<2>},
       Variant{"[row] SHIPPED small 2x4 (641..3583 rows)", k1::launch_small<4>},
       Variant{"[row] SHIPPED sched 64x128 (the opening rounds of glc_encode; 1793..4095 rows until round 3)", k1::launch_sched<64, 128, 16, 4>},
-      Variant{"[row] st 8 waves (>= 4096 rows)", k1::launch_st<4, 2, 1, 4>},
+      Variant{"[row] st 8 waves (>= 4096 rows)", st_v<4, 2, 1, 4>},
       // k_mdct_fwd_st: the table from SGPRs, lanes <-> rows (K1_FILTER='[cand]' K1_ROUNDS=4 compares interleaved)
       Variant{"[cand] dma 128x128 PRIO 1 (shipped until round 3), the channel count's own loader",
               [](const DeviceTables &t, const PcmView &p, uint64_t f0, uint32_t M, float *c, hipStream_t s) {
@@ -303,19 +345,19 @@ int main(int argc, char **argv) {
       // 4 i-steps per fetch hipcc ran out of scalar registers there and spilled table values into VGPR lanes
       // BETWEEN the scalar load and its s_waitcnt - stale values, wrong results, a memory fault: the case
       // tools/check_isa.py refuses for the shipped kernels)
-      Variant{"[cand] st 8 waves bk16 d2 PRIO 1", k1::launch_st<4, 2, 1>},
-      Variant{"[cand] st 16 waves bk32 d4 PRIO 2", k1::launch_st<4, 2, 2, 4, 16, 32>},
-      Variant{"[st] 8 waves bk16 d2 PRIO 0", k1::launch_st<4, 2, 0>},
-      Variant{"[st] 16 waves bk16 d2 PRIO 0", k1::launch_st<4, 2, 0, 2, 16, 16>},
-      Variant{"[st] 16 waves bk16 d4 PRIO 0", k1::launch_st<4, 2, 0, 4, 16, 16>},
-      Variant{"[st] 16 waves bk32 d2 PRIO 2", k1::launch_st<4, 2, 2, 2, 16, 32>},
+      Variant{"[cand] st 8 waves bk16 d2 PRIO 1", st_v<4, 2, 1>},
+      Variant{"[cand] st 16 waves bk32 d4 PRIO 2", st_v<4, 2, 2, 4, 16, 32>},
+      Variant{"[st] 8 waves bk16 d2 PRIO 0", st_v<4, 2, 0>},
+      Variant{"[st] 16 waves bk16 d2 PRIO 0", st_v<4, 2, 0, 2, 16, 16>},
+      Variant{"[st] 16 waves bk16 d4 PRIO 0", st_v<4, 2, 0, 4, 16, 16>},
+      Variant{"[st] 16 waves bk32 d2 PRIO 2", st_v<4, 2, 2, 2, 16, 32>},
       // ablations (results are wrong by construction)
-      Variant{"[abl] st 16 waves bk16 d4 PRIO 2: table address does not advance (scalar cache hits)", k1::launch_st<4, 2, 2, 4, 16, 16, 1>},
-      Variant{"[abl] st 16 waves bk16 d4 PRIO 2: no staging, no barrier", k1::launch_st<4, 2, 2, 4, 16, 16, 2>},
-      Variant{"[abl] st 16 waves bk16 d4 PRIO 2: neither", k1::launch_st<4, 2, 2, 4, 16, 16, 3>},
-      Variant{"[abl] st 8 waves bk16 d4 PRIO 1: table address does not advance", k1::launch_st<4, 2, 1, 4, 8, 16, 1>},
-      Variant{"[abl] st 8 waves bk16 d4 PRIO 1: no staging, no barrier", k1::launch_st<4, 2, 1, 4, 8, 16, 2>},
-      Variant{"[abl] st 8 waves bk16 d4 PRIO 1: neither", k1::launch_st<4, 2, 1, 4, 8, 16, 3>},
+      Variant{"[abl] st 16 waves bk16 d4 PRIO 2: table address does not advance (scalar cache hits)", st_v<4, 2, 2, 4, 16, 16, 1>},
+      Variant{"[abl] st 16 waves bk16 d4 PRIO 2: no staging, no barrier", st_v<4, 2, 2, 4, 16, 16, 2>},
+      Variant{"[abl] st 16 waves bk16 d4 PRIO 2: neither", st_v<4, 2, 2, 4, 16, 16, 3>},
+      Variant{"[abl] st 8 waves bk16 d4 PRIO 1: table address does not advance", st_v<4, 2, 1, 4, 8, 16, 1>},
+      Variant{"[abl] st 8 waves bk16 d4 PRIO 1: no staging, no barrier", st_v<4, 2, 1, 4, 8, 16, 2>},
+      Variant{"[abl] st 8 waves bk16 d4 PRIO 1: neither", st_v<4, 2, 1, 4, 8, 16, 3>},
       Variant{"SHIPPED sched 64x128 256thr (the opening rounds of glc_encode; 1793..4095 rows until round 3)", k1::launch_sched<64, 128, 16, 4>},
       Variant{"SHIPPED small 32x32 t2x2 256thr, hand-scheduled (<= 640 rows)", k1::launch_small<2>},
       Variant{"SHIPPED small 32x64 t2x4 256thr, hand-scheduled (641..3583 rows)", k1::launch_small<4>},
