@@ -35,7 +35,7 @@ BYTES_PER_SAMPLE = 4.0 + 2.0 + 6.0 / 1024.0  # f32 in + dense i16 out + {scale, 
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_PEAK_TFLOPS = 157.3           # f32 vector peak with FMA = 2 flop (MI355X_MICROARCH.md)
 F32_UNFUSED_TFLOPS = F32_PEAK_TFLOPS / 2.0  # separately rounded mul + add: one flop per issue slot
-K1_KERNEL = "glc::k1::k_mdct_fwd_st<4, 2, 2, 4, 16, 16, 0>"   # name in rocprofv3's kernel trace (stereo segment loader, priority by distance from the barrier, 4 i-steps per fetch, 16 waves)
+K1_KERNEL = "glc::k1::k_mdct_fwd_st<4, 2, 2, 4, 16, 16, 0, false>"   # name in rocprofv3's kernel trace (stereo segment loader, priority by distance from the barrier, 4 i-steps per fetch, 16 waves)
 D1_KERNEL = "glc::k_imdct_apply<true, true, true> on the kept plan (first decode of a stream: + k_imdct_plan + k_imdct_order)"
 
 

@@ -163,6 +163,16 @@ __global__ __launch_bounds__(256) void k_quantize(DeviceTables tb, const float *
     const float peak_gate = mul_rn(sc, 0.3f);      // global_max * 0.3, :232
     const float peak_cap = mul_rn(sc, 0.05f);      // global_max * 0.05, :234
     unsigned cnt = 0;
+    // the 16 band bases of this lane's bins, fetched together: left to the compiler, each of the 16 LDS reads
+    // sits directly in front of its use and is waited for there (64 exposed LDS round trips per wave)
+    float sb[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sb[j][e] = sbase[w][r][bo[j][e]];
+    asm volatile("" : "+v"(sb[0][0]), "+v"(sb[0][1]), "+v"(sb[0][2]), "+v"(sb[0][3]), "+v"(sb[1][0]), "+v"(sb[1][1]),
+                      "+v"(sb[1][2]), "+v"(sb[1][3]), "+v"(sb[2][0]), "+v"(sb[2][1]), "+v"(sb[2][2]), "+v"(sb[2][3]),
+                      "+v"(sb[3][0]), "+v"(sb[3][1]), "+v"(sb[3][2]), "+v"(sb[3][3]));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float cv[4] = {c4[r][j].x, c4[r][j].y, c4[r][j].z, c4[r][j].w};
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(256) void k_quantize(DeviceTables tb, const float *
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float a = fabsf(cv[e]);
-        float t = mul_rn(sbase[w][r][bo[j][e]], iv[e]);             // :228-229
+        float t = mul_rn(sb[j][e], iv[e]);                           // :228-229
         if (a > peak_gate) t = fminf(t, peak_cap);                  // :232-235
         const float thr = mul_rn(t, sc);                            // :288
         short q = 0;

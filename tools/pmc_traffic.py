@@ -101,7 +101,7 @@ def main():
     fw = factors["calib_write_rows"]["counter_bytes_per_true_byte"]
     k1 = kernels["K1"]
     out = {
-        "kernel": "glc::k1::k_mdct_fwd_st<4, 2, 2, 4, 16, 16, 0> (256x128 tile, 1024 threads, table values by scalar loads, PCM by dwordx4 segments)",
+        "kernel": "glc::k1::k_mdct_fwd_st<4, 2, 2, 4, 16, 16, 0, false> (256x128 tile, 1024 threads, table values by scalar loads, PCM by dwordx4 segments)",
         "commit": args.commit,
         "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --steps 10, corrected by the "
                   "factors tools/fetch_calib.hip measures for K1's own access patterns in the same session",
